@@ -1,0 +1,524 @@
+"""torch.autograd bridges onto the C ABI of libagan_hip.so.
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and the autograd
+tape.  Every numerical op on the hot path is a hand-written gfx950 kernel reached through `lib.call`.
+All tensors are NCHW fp32 like the reference's.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import byref, c_void_p
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib as L
+
+# arithmetic mode used by the MFMA contractions; PREC_F32 = exact fp32 products (parity mode, the default)
+_PRECISION = [L.PREC_F32]
+
+
+def set_precision(p: int) -> None:
+    _PRECISION[0] = int(p)
+
+
+def get_precision() -> int:
+    return _PRECISION[0]
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]) -> Optional[c_void_p]:
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _dev(t: Tensor, what: str) -> Tensor:
+    if not t.is_cuda:
+        raise L.AganError(f"{what}: tensor is on {t.device}; the AttnGAN HIP path runs on an MI355X only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise L.AganError(f"{what}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ws(nbytes: int, like: Tensor) -> Tuple[Optional[Tensor], Optional[c_void_p]]:
+    if nbytes <= 0:
+        return None, None
+    t = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+    return t, c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# convolution geometry (see include/agan.h: agan_conv_geom)
+# --------------------------------------------------------------------------------------------------------------
+def _geom(B, Cin, IH, IW, Cout, OH, OW, R, S, OS, SY, DY, OY) -> L.ConvGeom:
+    g = L.ConvGeom()
+    g.B, g.Cin, g.IH, g.IW, g.Cout, g.OH, g.OW = B, Cin, IH, IW, Cout, OH, OW
+    g.R, g.S, g.OS, g.SY, g.DY = R, S, OS, SY, DY
+    g.OY[0], g.OY[1] = OY
+    return g
+
+
+_GEOM_CACHE = {}
+
+
+def conv_geoms(kind: str, B: int, Cin: int, H: int, W: int, Cout: int, k: int):
+    """-> (fwd geom, fwd pack mode, dgrad geom, dgrad pack mode, (OH, OW)) for the conv kinds on the path.
+
+    same : k x k, stride 1, pad (k-1)/2          utilities/layers.py:45-53 (and nn.Linear as 1x1 on a 1x1 image)
+    down : 4 x 4, stride 2, pad 1                utilities/layers.py:122,139-150
+    up   : nearest x2 upsample then 3x3 pad 1    utilities/layers.py:64-65, folded into 4 parity classes of 2x2 taps
+    """
+    key = (kind, B, Cin, H, W, Cout, k)
+    hit = _GEOM_CACHE.get(key)
+    if hit is not None:
+        return hit
+    if kind == "same":
+        p = (k - 1) // 2
+        out = (_geom(B, Cin, H, W, Cout, H, W, k, k, 1, 1, 1, (-p, -p)), L.PACK_FWD,
+               _geom(B, Cout, H, W, Cin, H, W, k, k, 1, 1, 1, (-p, -p)), L.PACK_DGRAD_S1, (H, W))
+    elif kind == "down":
+        if k != 4 or H % 2 or W % 2:
+            raise L.AganError(f"down conv needs k=4 and even H,W (got k={k}, {H}x{W})")
+        out = (_geom(B, Cin, H, W, Cout, H // 2, W // 2, 4, 4, 1, 2, 1, (-1, -1)), L.PACK_FWD,
+               _geom(B, Cout, H // 2, W // 2, Cin, H, W, 2, 2, 2, 1, -1, (0, 1)), L.PACK_DGRAD_4x4S2, (H // 2, W // 2))
+    elif kind == "up":
+        if k != 3:
+            raise L.AganError("upsample conv needs k=3")
+        out = (_geom(B, Cin, H, W, Cout, 2 * H, 2 * W, 2, 2, 2, 1, 1, (-1, 0)), L.PACK_UP_FWD,
+               _geom(B, Cout, 2 * H, 2 * W, Cin, H, W, 4, 4, 1, 2, 1, (-1, -1)), L.PACK_UP_DGRAD, (2 * H, 2 * W))
+    else:
+        raise L.AganError(f"unknown conv kind {kind!r}")
+    _GEOM_CACHE[key] = out
+    return out
+
+
+# Packed weights are cached per owning module (a plain dict the module passes in): a parameter is re-packed only when
+# it changed -- in-place version bump (load_state_dict), new storage (.to(), FlatAdam re-homing) or an optimiser step
+# that wrote through the raw pointer and therefore bumped the global epoch.  Without a cache dict every call re-packs.
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch() -> None:
+    _WEIGHT_EPOCH[0] += 1
+
+
+def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
+    cout, cin, kh, kw = w.shape
+    ver = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0], cout, cin, kh, kw)
+    hit = cache.get(mode) if cache is not None else None
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    n = L.load().agan_packed_weight_elems(mode, cout, cin, kh, kw)
+    if n == 0:
+        raise L.AganError(f"pack mode {mode} does not take a {kh}x{kw} kernel")
+    reuse = hit is not None and hit[1].numel() == n and hit[1].device == w.device
+    wk = hit[1] if reuse else torch.empty(n, dtype=torch.float32, device=w.device)
+    L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, _stream())
+    if cache is not None:
+        cache[mode] = (ver, wk)
+    return wk
+
+
+def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor) -> None:
+    lib = L.load()
+    nbytes = lib.agan_conv_gather_ws_bytes(byref(g))
+    ws, wsp = _ws(nbytes, x)
+    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _PRECISION[0], wsp, nbytes, _stream())
+
+
+class _ConvFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict]):
+        x = _dev(x, "conv input")
+        w = _dev(weight.detach(), "conv weight")
+        B, Cin, H, W = x.shape
+        Cout, Cin_w, kh, kw = w.shape
+        if Cin != Cin_w or kh != kw:
+            raise L.AganError(f"conv: input has {Cin} channels, weight {tuple(w.shape)}")
+        gf, pf, gd, pd, (OH, OW) = conv_geoms(kind, B, Cin, H, W, Cout, kh)
+        out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        b = _dev(bias.detach(), "conv bias") if bias is not None else None
+        _gather(x, packed_weight(w, pf, cache), b, gf, out)
+        ctx.save_for_backward(x, w)
+        ctx.kind, ctx.has_bias, ctx.cache = kind, bias is not None, cache
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy: Tensor):
+        x, w = ctx.saved_tensors
+        dy = _dev(dy, "conv grad")
+        B, Cin, H, W = x.shape
+        Cout, _, kh, kw = w.shape
+        gf, pf, gd, pd, _ = conv_geoms(ctx.kind, B, Cin, H, W, Cout, kh)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            lib = L.load()
+            nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
+            ws, wsp = _ws(nbytes, x)
+            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dw), byref(gf), pf, kh, kw, _PRECISION[0], wsp, nbytes, _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            L.call("agan_bias_grad", _p(dy), _p(db), B, Cout, dy.shape[2] * dy.shape[3], _stream())
+        return dx, dw, db, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None) -> Tensor:
+    """conv forward with autograd (dgrad + wgrad kernels).  kind: 'same' | 'down' | 'up' (conv_geoms)."""
+    return _ConvFn.apply(x, weight, bias, kind, cache)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Optional[dict] = None) -> Tensor:
+    """nn.Linear as a 1x1 conv on a 1x1 image (generator_submodules.py:36,152)."""
+    B, Cin = x.shape
+    y = _ConvFn.apply(x.reshape(B, Cin, 1, 1), weight.view(weight.shape[0], Cin, 1, 1), bias, "same", cache)
+    return y.view(B, weight.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BatchNorm (train mode) + activation
+# --------------------------------------------------------------------------------------------------------------
+class _BnActFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum):
+        x = _dev(x, "bn input")
+        shape = x.shape
+        B, C = shape[0], shape[1]
+        HW = x.numel() // (B * C)
+        g, b = _dev(gamma.detach(), "bn weight"), _dev(beta.detach(), "bn bias")
+        lib = L.load()
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            nbytes = lib.agan_bn_stats_ws_bytes(B, C, HW)
+            ws, wsp = _ws(nbytes, x)
+            L.call("agan_bn_stats", _p(x), B, C, HW, float(eps), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                   _p(nbt), float(momentum), wsp, nbytes, _stream())
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        co = C // 2 if act == L.ACT_GLU else C
+        out = torch.empty((B, co) + tuple(shape[2:]), dtype=torch.float32, device=x.device)
+        res = _dev(residual, "bn residual") if residual is not None else None
+        L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
+        ctx.save_for_backward(x, g, b, mean, invstd)
+        ctx.act, ctx.training, ctx.has_res = act, training, residual is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise L.AganError("BatchNorm backward in eval mode is not on the training path")
+        x, g, b, mean, invstd = ctx.saved_tensors
+        dout = _dev(dout, "bn grad")
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(g), torch.empty_like(b)
+        nbytes = L.load().agan_bn_act_bwd_ws_bytes(B, C, HW)
+        ws, wsp = _ws(nbytes, x)
+        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dg), _p(db), B, C, HW,
+               ctx.act, wsp, nbytes, _stream())
+        dres = dout if ctx.has_res else None
+        return dx, dg, db, dres, None, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, nbt, training: bool, act: int, residual=None,
+           eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+    return _BnActFn.apply(x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum)
+
+
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _dev(x, "activation input")
+        out = torch.empty_like(x)
+        L.call("agan_act_fwd", _p(x), _p(out), x.numel(), act, _stream())
+        ctx.save_for_backward(out)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = _dev(dout, "activation grad")
+        dx = torch.empty_like(out)
+        L.call("agan_act_bwd", _p(out), _p(dout), _p(dx), out.numel(), ctx.act, _stream())
+        return dx, None
+
+
+def activation(x: Tensor, act: int) -> Tensor:
+    return _ActFn.apply(x, act)
+
+
+class _GluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, "GLU input")
+        B, C = x.shape[0], x.shape[1]
+        if C % 2:
+            raise AssertionError("channels dont divide 2!")      # utilities/layers.py:22
+        HW = x.numel() // (B * C)
+        out = torch.empty((B, C // 2) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        L.call("agan_glu_fwd", _p(x), _p(out), B, C, HW, _stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dout = _dev(dout, "GLU grad")
+        B, C = x.shape[0], x.shape[1]
+        dx = torch.empty_like(x)
+        L.call("agan_glu_bwd", _p(x), _p(dout), _p(dx), B, C, x.numel() // (B * C), _stream())
+        return dx
+
+
+def glu(x: Tensor) -> Tensor:
+    return _GluFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# word-context attention (networks/attention.py:25-79)
+# --------------------------------------------------------------------------------------------------------------
+class _AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, images, words, weight, mask, scale):
+        images, words = _dev(images, "attention images"), _dev(words, "attention words")
+        w = _dev(weight.detach(), "attention conv1 weight")
+        B, C, H, W = images.shape
+        Bw, E, T = words.shape
+        if Bw != B or tuple(mask.shape) != (B, T):
+            raise ValueError(f"attention: images {tuple(images.shape)}, words {tuple(words.shape)}, mask {tuple(mask.shape)}")
+        m = mask.to(device=images.device, dtype=torch.int64).contiguous()
+        proj = torch.empty((B, C, T), dtype=torch.float32, device=images.device)
+        ctxt = torch.empty_like(images)
+        attn = torch.empty((B, T, H, W), dtype=torch.float32, device=images.device)
+        L.call("agan_attn_fwd", _p(images), _p(words), _p(w), _p(m), float(scale), _p(proj), _p(ctxt), _p(attn),
+               B, C, E, T, H * W, _stream())
+        ctx.save_for_backward(images, words, w, proj, attn)
+        ctx.scale = float(scale)
+        return ctxt, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dctx, dattn):
+        images, words, w, proj, attn = ctx.saved_tensors
+        B, C, H, W = images.shape
+        _, E, T = words.shape
+        dctx = _dev(dctx, "attention dctx") if dctx is not None else None
+        dattn = _dev(dattn, "attention dattn") if dattn is not None else None
+        dimages, dwords, dw = torch.empty_like(images), torch.empty_like(words), torch.empty_like(w)
+        nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T)
+        ws, wsp = _ws(nbytes, images)
+        L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
+               _p(dimages), _p(dwords), _p(dw), B, C, E, T, H * W, wsp, nbytes, _stream())
+        return dimages, dwords, dw.view_as(w), None, None
+
+
+def attention(images: Tensor, words: Tensor, conv1_weight: Tensor, mask: Tensor, scaled: bool = True):
+    C = images.shape[1]
+    scale = 1.0 / math.sqrt(C) if scaled else 1.0
+    return _AttentionFn.apply(images, words, conv1_weight, mask, scale)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# small heads
+# --------------------------------------------------------------------------------------------------------------
+class _ReparamFn(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _dev(mu, "mu"), _dev(logvar, "logvar"), _dev(eps, "eps")
+        c = torch.empty_like(mu)
+        L.call("agan_reparam_fwd", _p(mu), _p(logvar), _p(eps), _p(c), mu.numel(), _stream())
+        ctx.save_for_backward(logvar, eps)
+        return c
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dc):
+        logvar, eps = ctx.saved_tensors
+        dc = _dev(dc, "dc")
+        dmu, dlv = torch.empty_like(dc), torch.empty_like(dc)
+        L.call("agan_reparam_bwd", _p(logvar), _p(eps), _p(dc), _p(dmu), _p(dlv), dc.numel(), _stream())
+        return dmu, dlv, None
+
+
+def reparametrize(mu, logvar, eps):
+    return _ReparamFn.apply(mu, logvar, eps)
+
+
+class _DiscLossFn(Function):
+    @staticmethod
+    def forward(ctx, p_real, p_fake):
+        p_real, p_fake = _dev(p_real, "D(x)"), _dev(p_fake, "D(G(z))")
+        loss = torch.empty((), dtype=torch.float32, device=p_real.device)
+        dr, df = torch.empty_like(p_real), torch.empty_like(p_fake)
+        L.call("agan_disc_loss", _p(p_real), _p(p_fake), _p(loss), _p(dr), _p(df), p_real.numel(), _stream())
+        ctx.save_for_backward(dr, df)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dr, df = ctx.saved_tensors
+        return dr * g, df * g
+
+
+def ns_disc_loss(p_real, p_fake):
+    return _DiscLossFn.apply(p_real, p_fake)
+
+
+class _GenLossFn(Function):
+    @staticmethod
+    def forward(ctx, p_fake):
+        p_fake = _dev(p_fake, "D(G(z))")
+        loss = torch.empty((), dtype=torch.float32, device=p_fake.device)
+        df = torch.empty_like(p_fake)
+        L.call("agan_gen_loss", _p(p_fake), _p(loss), _p(df), p_fake.numel(), _stream())
+        ctx.save_for_backward(df)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return df * g
+
+
+def ns_gen_loss(p_fake):
+    return _GenLossFn.apply(p_fake)
+
+
+class _KLFn(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _dev(mu, "mu"), _dev(logvar, "logvar")
+        loss = torch.empty((), dtype=torch.float32, device=mu.device)
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        L.call("agan_kl_loss", _p(mu), _p(logvar), _p(loss), _p(dmu), _p(dlv), mu.numel(), _stream())
+        ctx.save_for_backward(dmu, dlv)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dmu, dlv = ctx.saved_tensors
+        return dmu * g, dlv * g
+
+
+def kl_loss(mu, logvar):
+    return _KLFn.apply(mu, logvar)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# DAMSM losses (losses/words_loss.py:29-102, losses/sentence_loss.py:12-50)
+# --------------------------------------------------------------------------------------------------------------
+def _ids(class_ids, device) -> Optional[Tensor]:
+    if class_ids is None:
+        return None
+    return torch.as_tensor(class_ids).to(device=device, dtype=torch.int64).contiguous()
+
+
+def func_attention(query: Tensor, context: Tensor, gamma1: float = 4.0, scaled: bool = True):
+    """Forward of the parameter-free DAMSM attention (attention.py:82-120).  Inside the training step it only ever runs
+    fused into the words-loss kernels, which carry its backward; the standalone entry point is forward-only."""
+    q, c = _dev(query.detach(), "query"), _dev(context.detach(), "context")
+    B, D, Lq = q.shape
+    ih, iw = c.shape[2], c.shape[3]
+    wctx = torch.empty((B, D, Lq), dtype=torch.float32, device=q.device)
+    attn = torch.empty((B, Lq, ih, iw), dtype=torch.float32, device=q.device)
+    L.call("agan_func_attention_fwd", _p(q), _p(c), float(gamma1), (1.0 / math.sqrt(D)) if scaled else 1.0, _p(wctx), _p(attn),
+           B, D, Lq, ih * iw, _stream())
+    return wctx, attn
+
+
+class _WordsLossFn(Function):
+    @staticmethod
+    def forward(ctx, feat, wemb, lens, cids, g1, g2, g3, lam):
+        feat, wemb = _dev(feat, "img_features"), _dev(wemb, "words_emb")
+        B, D = feat.shape[0], feat.shape[1]
+        S = feat.numel() // (B * D)
+        T = wemb.shape[2]
+        loss = torch.empty((), dtype=torch.float32, device=feat.device)
+        sim = torch.empty((B, B), dtype=torch.float32, device=feat.device)
+        maps = torch.zeros((B, T, S), dtype=torch.float32, device=feat.device)
+        save = torch.empty(L.load().agan_words_loss_save_elems(B, D, T, S), dtype=torch.float32, device=feat.device)
+        L.call("agan_words_loss_fwd", _p(feat), _p(wemb), _p(lens), _p(cids), g1, g2, g3, lam, _p(loss), _p(sim), _p(maps),
+               _p(save), B, D, T, S, _stream())
+        ctx.save_for_backward(feat, wemb, lens, save)
+        ctx.hp = (g1, g2, g3, lam)
+        ctx.mark_non_differentiable(maps, sim)
+        return loss, maps, sim
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss, _dmaps, _dsim):
+        feat, wemb, lens, save = ctx.saved_tensors
+        B, D = feat.shape[0], feat.shape[1]
+        S = feat.numel() // (B * D)
+        T = wemb.shape[2]
+        dfeat, dwemb = torch.zeros_like(feat), torch.zeros_like(wemb)
+        dl = dloss.to(torch.float32).contiguous()
+        L.call("agan_words_loss_bwd", _p(feat), _p(wemb), _p(lens), _p(save), _p(dl), *ctx.hp, _p(dfeat), _p(dwemb),
+               B, D, T, S, _stream())
+        return dfeat, dwemb, None, None, None, None, None, None
+
+
+def words_loss(feat, wemb, cap_lens, class_ids, gamma1, gamma2, gamma3, wlambda):
+    lens = torch.as_tensor(cap_lens).to(device=feat.device, dtype=torch.int64).contiguous()
+    return _WordsLossFn.apply(feat, wemb, lens, _ids(class_ids, feat.device), float(gamma1), float(gamma2), float(gamma3),
+                              float(wlambda))
+
+
+class _SentLossFn(Function):
+    @staticmethod
+    def forward(ctx, cnn, rnn, cids, g3, lam, eps):
+        cnn, rnn = _dev(cnn, "cnn_code"), _dev(rnn, "rnn_code")
+        B, D = cnn.shape
+        loss = torch.empty((), dtype=torch.float32, device=cnn.device)
+        save = torch.empty(2 * B * B + 2 * B, dtype=torch.float32, device=cnn.device)
+        L.call("agan_sent_loss_fwd", _p(cnn), _p(rnn), _p(cids), g3, lam, eps, _p(loss), _p(save), B, D, _stream())
+        ctx.save_for_backward(cnn, rnn, save)
+        ctx.hp = (g3, lam, eps)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        cnn, rnn, save = ctx.saved_tensors
+        B, D = cnn.shape
+        dc, dr = torch.empty_like(cnn), torch.empty_like(rnn)
+        dl = dloss.to(torch.float32).contiguous()
+        L.call("agan_sent_loss_bwd", _p(cnn), _p(rnn), _p(save), _p(dl), *ctx.hp, _p(dc), _p(dr), B, D, _stream())
+        return dc, dr, None, None, None, None
+
+
+def sentence_loss(cnn_code, rnn_code, class_ids, gamma3, slambda, eps=1e-8):
+    return _SentLossFn.apply(cnn_code, rnn_code, _ids(class_ids, cnn_code.device), float(gamma3), float(slambda), float(eps))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# fused Adam on a flat buffer
+# --------------------------------------------------------------------------------------------------------------
+def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float, beta1: float,
+               beta2: float, eps: float, grad_scale: float = 1.0) -> None:
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise L.AganError("adam_step_: flat contiguous float32 device buffers required")
+    L.call("agan_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step), float(lr),
+           float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
+    bump_weight_epoch()

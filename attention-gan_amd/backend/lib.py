@@ -1,0 +1,98 @@
+"""ctypes binding of libagan_hip.so (C ABI declared in include/agan.h).
+
+The product path has no CPU fallback: if the shared library is missing or the tensors are not on an
+MI355X the calls raise.  Only raw device pointers, sizes and the current HIP stream cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libagan_hip.so")
+
+# enums of include/agan.h
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_4x4S2, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class ConvGeom(Structure):
+    """struct agan_conv_geom."""
+    _fields_ = [("B", c_int32), ("Cin", c_int32), ("IH", c_int32), ("IW", c_int32),
+                ("Cout", c_int32), ("OH", c_int32), ("OW", c_int32), ("R", c_int32), ("S", c_int32),
+                ("OS", c_int32), ("SY", c_int32), ("DY", c_int32), ("OY", c_int32 * 2)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "agan_version": (c_int, []),
+    "agan_last_error": (c_char_p, []),
+    "agan_packed_weight_elems": (c_size_t, [c_int] * 5),
+    "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
+    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), c_int, _P, c_size_t, _P]),
+    "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
+    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_bn_act_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "agan_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "agan_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "agan_glu_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "agan_attn_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "agan_attn_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "agan_attn_bwd": (c_int, [_P] * 7 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_func_attention_fwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_words_loss_save_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "agan_words_loss_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_words_loss_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_sent_loss_fwd": (c_int, [_P, _P, _P, c_float, c_float, c_float, _P, _P, c_int, c_int, _P]),
+    "agan_sent_loss_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, c_int, c_int, _P]),
+    "agan_disc_loss": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
+    "agan_gen_loss": (c_int, [_P, _P, _P, c_int, _P]),
+    "agan_kl_loss": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
+    "agan_reparam_fwd": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "agan_reparam_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
+    "agan_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_double, c_double, c_double, c_double, c_float, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class AganError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libagan_hip.so and attach prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AganError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(or `make -C attention-gan_amd/csrc`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().agan_last_error()
+        raise AganError(f"{what or 'agan'} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

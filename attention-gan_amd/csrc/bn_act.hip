@@ -1,0 +1,514 @@
+// Train-mode BatchNorm (+GLU / LeakyReLU / residual) forward and backward, plus the bare activations.
+// HBM-bound streaming kernels over NCHW fp32: lanes run along the contiguous pixel axis with 16-B accesses; the
+// per-channel reductions accumulate in fp64 per thread (the kernels are bandwidth-bound, the DP adds are free)
+// so that var = E[x^2] - mean^2 does not cancel.
+#include "agan_common.h"
+
+#include <algorithm>
+
+using namespace agan;
+
+namespace {
+
+constexpr float kSlope = 0.2f;   // LeakyReLU slope, utilities/layers.py:124
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// ---- chunked per-channel reduction driver -----------------------------------------------------------------
+// Calls f(x_index, flat_pixel_index, vec) for every element of channel c inside [beg, end) of the (b, p) space.
+struct Chunk { int beg, end; };
+
+__device__ __forceinline__ Chunk chunk_of(int n, int nchunk, int chunk) {
+    int len = (cdiv(n, nchunk) + 3) & ~3;
+    Chunk c;
+    c.beg = min(n, chunk * len);
+    c.end = min(n, c.beg + len);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// statistics
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int B, int C, int HW, int nchunk,
+                                                               double* __restrict__ part) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int n = B * HW;
+    const Chunk ch = chunk_of(n, nchunk, chunk);
+    double s = 0.0, q = 0.0;
+    if ((HW & 3) == 0) {
+        for (int i = ch.beg + threadIdx.x * 4; i < ch.end; i += 1024) {
+            const int b = i / HW, p = i - b * HW;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + p);
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (int i = ch.beg + threadIdx.x; i < ch.end; i += 256) {
+            const int b = i / HW, p = i - b * HW;
+            const float v = x[((size_t)b * C + c) * HW + p];
+            s += v;
+            q += (double)v * v;
+        }
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s; red[1][w] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)c * nchunk + chunk) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((size_t)c * nchunk + chunk) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int C, int nchunk, int n, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar,
+                                                             int64_t* __restrict__ nbt, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s += part[((size_t)c * nchunk + k) * 2 + 0];
+        q += part[((size_t)c * nchunk + k) * 2 + 1];
+    }
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unbiased = n > 1 ? var * ((double)n / (n - 1)) : var;
+        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
+    }
+}
+
+// HW == 1 (BatchNorm1d on [B, C], generator_submodules.py:38): one thread per channel, coalesced across channels
+__global__ __launch_bounds__(256) void bn_stats_rows_kernel(const float* __restrict__ x, int B, int C, float eps,
+                                                            float* __restrict__ mean, float* __restrict__ invstd,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar,
+                                                            int64_t* __restrict__ nbt, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float v = x[(size_t)b * C + c];
+        s += v;
+        q += (double)v * v;
+    }
+    const double m = s / B;
+    double var = q / B - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unbiased = B > 1 ? var * ((double)B / (B - 1)) : var;
+        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
+    }
+}
+
+int stats_chunks(int B, int C, int HW) {
+    const int n = B * HW;
+    int nchunk = std::max(1, 2048 / std::max(C, 1));
+    nchunk = std::min(nchunk, std::max(1, n / 2048));
+    return nchunk;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward apply
+// ---------------------------------------------------------------------------------------------------------
+struct Affine { float s, t; };
+__device__ __forceinline__ Affine affine_of(const float* mean, const float* invstd, const float* gamma, const float* beta, int c) {
+    Affine a;
+    a.s = gamma[c] * invstd[c];
+    a.t = beta[c] - mean[c] * a.s;
+    return a;
+}
+
+template <int ACT, bool VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ res,
+                                                         float* __restrict__ out, int B, int C, int HW) {
+    constexpr int V = VEC ? 4 : 1;
+    const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
+    const size_t total = (size_t)B * Co * HW / V;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e * V;
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % Co), b = (int)(t / Co);
+        const size_t xi = ((size_t)b * C + c) * HW + p;
+        const Affine a = affine_of(mean, invstd, gamma, beta, c);
+        float xv[4], yv[4];
+        if (VEC) *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + xi);
+        else xv[0] = x[xi];
+        if (ACT == AGAN_ACT_GLU) {
+            const Affine g = affine_of(mean, invstd, gamma, beta, c + Co);
+            float gv[4];
+            const size_t gi = xi + (size_t)Co * HW;
+            if (VEC) *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(x + gi);
+            else gv[0] = x[gi];
+#pragma unroll
+            for (int k = 0; k < V; ++k) yv[k] = (xv[k] * a.s + a.t) * sigmoidf_(gv[k] * g.s + g.t);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float z = xv[k] * a.s + a.t;
+                if (ACT == AGAN_ACT_LRELU) z = z >= 0.f ? z : z * kSlope;
+                yv[k] = z;
+            }
+            if (res) {
+                float rv[4];
+                if (VEC) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + i);
+                else rv[0] = res[i];
+#pragma unroll
+                for (int k = 0; k < V; ++k) yv[k] += rv[k];
+            }
+        }
+        if (VEC) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<float4*>(yv);
+        else out[i] = yv[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: pass 1 = per-channel sums of dz and dz*xhat, pass 2 = dx
+// ---------------------------------------------------------------------------------------------------------
+// dz for one element.  GLU: returns dz of the value half in dza and of the gate half in dzg.
+template <int ACT>
+__device__ __forceinline__ void dz_of(float xa, float xg, float d, const Affine& a, const Affine& g, float& dza, float& dzg) {
+    if (ACT == AGAN_ACT_GLU) {
+        const float za = xa * a.s + a.t;
+        const float sg = sigmoidf_(xg * g.s + g.t);
+        dza = d * sg;
+        dzg = d * za * sg * (1.f - sg);
+    } else if (ACT == AGAN_ACT_LRELU) {
+        const float z = xa * a.s + a.t;
+        dza = z >= 0.f ? d : d * kSlope;
+        dzg = 0.f;
+    } else {
+        dza = d;
+        dzg = 0.f;
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int B, int C, int HW, int nchunk, double* __restrict__ part) {
+    // GLU: block handles the channel pair (c, c+C/2).  part[c][chunk][4] = {sum dz_a, sum dz_a*xhat_a, sum dz_g, sum dz_g*xhat_g}
+    __shared__ double red[4][4];
+    const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int n = B * HW;
+    const Chunk ch = chunk_of(n, nchunk, chunk);
+    const Affine a = affine_of(mean, invstd, gamma, beta, c);
+    const Affine g = (ACT == AGAN_ACT_GLU) ? affine_of(mean, invstd, gamma, beta, c + Co) : a;
+    const float ma = mean[c], ia = invstd[c];
+    const float mg = (ACT == AGAN_ACT_GLU) ? mean[c + Co] : 0.f, ig = (ACT == AGAN_ACT_GLU) ? invstd[c + Co] : 0.f;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const bool vec = (HW & 3) == 0;
+    const int step = vec ? 4 : 1;
+    for (int i = ch.beg + threadIdx.x * step; i < ch.end; i += 256 * step) {
+        const int b = i / HW, p = i - b * HW;
+        const size_t xi = ((size_t)b * C + c) * HW + p, di = ((size_t)b * Co + c) * HW + p;
+        float xa[4], xg[4] = {0, 0, 0, 0}, d[4];
+        if (vec) {
+            *reinterpret_cast<float4*>(xa) = *reinterpret_cast<const float4*>(x + xi);
+            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dout + di);
+            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = *reinterpret_cast<const float4*>(x + xi + (size_t)Co * HW);
+        } else {
+            xa[0] = x[xi];
+            d[0] = dout[di];
+            if (ACT == AGAN_ACT_GLU) xg[0] = x[xi + (size_t)Co * HW];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= step) break;
+            float dza, dzg;
+            dz_of<ACT>(xa[k], xg[k], d[k], a, g, dza, dzg);
+            s0 += dza;
+            s1 += (double)dza * ((xa[k] - ma) * ia);
+            if (ACT == AGAN_ACT_GLU) {
+                s2 += dzg;
+                s3 += (double)dzg * ((xg[k] - mg) * ig);
+            }
+        }
+    }
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    if (ACT == AGAN_ACT_GLU) { s2 = wave_sum_d(s2); s3 = wave_sum_d(s3); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; red[3][w] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        part[((size_t)c * nchunk + chunk) * 4 + k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+    }
+}
+
+// coef[c] = {mean dz, mean dz*xhat}; dgamma, dbeta
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int C, int Co, int nchunk, int n, bool glu,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int pc = (glu && c >= Co) ? c - Co : c;
+    const int off = (glu && c >= Co) ? 2 : 0;
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        s += part[((size_t)pc * nchunk + k) * 4 + off];
+        q += part[((size_t)pc * nchunk + k) * 4 + off + 1];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    coef[2 * c] = (float)(s / n);
+    coef[2 * c + 1] = (float)(q / n);
+}
+
+template <int ACT, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ coef, float* __restrict__ dx, int B, int C, int HW) {
+    constexpr int V = VEC ? 4 : 1;
+    const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
+    const size_t total = (size_t)B * Co * HW / V;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e * V;
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % Co), b = (int)(t / Co);
+        const size_t xi = ((size_t)b * C + c) * HW + p;
+        const Affine a = affine_of(mean, invstd, gamma, beta, c);
+        const Affine g = (ACT == AGAN_ACT_GLU) ? affine_of(mean, invstd, gamma, beta, c + Co) : a;
+        const float ma = mean[c], ia = invstd[c], c0 = coef[2 * c], c1 = coef[2 * c + 1];
+        float xa[4], xg[4] = {0, 0, 0, 0}, d[4], oa[4], og[4];
+        if (VEC) {
+            *reinterpret_cast<float4*>(xa) = *reinterpret_cast<const float4*>(x + xi);
+            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dout + i);
+            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = *reinterpret_cast<const float4*>(x + xi + (size_t)Co * HW);
+        } else {
+            xa[0] = x[xi];
+            d[0] = dout[i];
+            if (ACT == AGAN_ACT_GLU) xg[0] = x[xi + (size_t)Co * HW];
+        }
+        float mg = 0, ig = 0, g0 = 0, g1 = 0;
+        if (ACT == AGAN_ACT_GLU) { mg = mean[c + Co]; ig = invstd[c + Co]; g0 = coef[2 * (c + Co)]; g1 = coef[2 * (c + Co) + 1]; }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float dza, dzg;
+            dz_of<ACT>(xa[k], xg[k], d[k], a, g, dza, dzg);
+            oa[k] = a.s * (dza - c0 - (xa[k] - ma) * ia * c1);
+            if (ACT == AGAN_ACT_GLU) og[k] = g.s * (dzg - g0 - (xg[k] - mg) * ig * g1);
+        }
+        if (VEC) {
+            *reinterpret_cast<float4*>(dx + xi) = *reinterpret_cast<float4*>(oa);
+            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(dx + xi + (size_t)Co * HW) = *reinterpret_cast<float4*>(og);
+        } else {
+            dx[xi] = oa[0];
+            if (ACT == AGAN_ACT_GLU) dx[xi + (size_t)Co * HW] = og[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bare activations
+// ---------------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float act1(float v) {
+    if (ACT == AGAN_ACT_LRELU) return v >= 0.f ? v : v * kSlope;
+    if (ACT == AGAN_ACT_TANH) return tanhf(v);
+    if (ACT == AGAN_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+// derivative expressed from the OUTPUT y (lrelu keeps the sign, so y works there too)
+template <int ACT>
+__device__ __forceinline__ float dact1(float y, float d) {
+    if (ACT == AGAN_ACT_LRELU) return y >= 0.f ? d : d * kSlope;
+    if (ACT == AGAN_ACT_TANH) return d * (1.f - y * y);
+    if (ACT == AGAN_ACT_SIGMOID) return d * y * (1.f - y);
+    return d;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = act1<ACT>(v.x); v.y = act1<ACT>(v.y); v.z = act1<ACT>(v.z); v.w = act1<ACT>(v.w);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = act1<ACT>(x[n4 * 4 + threadIdx.x]);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ d, float* __restrict__ dx, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 yv = reinterpret_cast<const float4*>(y)[i], dv = reinterpret_cast<const float4*>(d)[i];
+        float4 o;
+        o.x = dact1<ACT>(yv.x, dv.x); o.y = dact1<ACT>(yv.y, dv.y); o.z = dact1<ACT>(yv.z, dv.z); o.w = dact1<ACT>(yv.w, dv.w);
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t e = n4 * 4 + threadIdx.x;
+        dx[e] = dact1<ACT>(y[e], d[e]);
+    }
+}
+
+// standalone GLU (the CA-net "relu" is a GLU: generator_submodules.py:153; layers.py:20-24)
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW) {
+    const int Co = C / 2;
+    const size_t total = (size_t)B * Co * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t plane = (size_t)Co * HW, b = i / plane, r = i - b * plane;
+        const size_t xi = b * 2 * plane + r;
+        out[i] = x[xi] * sigmoidf_(x[xi + plane]);
+    }
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
+                                                      int B, int C, int HW) {
+    const int Co = C / 2;
+    const size_t total = (size_t)B * Co * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t plane = (size_t)Co * HW, b = i / plane, r = i - b * plane;
+        const size_t xi = b * 2 * plane + r;
+        const float a = x[xi], sg = sigmoidf_(x[xi + plane]), d = dout[i];
+        dx[xi] = d * sg;
+        dx[xi + plane] = d * a * sg * (1.f - sg);
+    }
+}
+
+int ew_blocks(size_t work) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(work, 256), 256 * 8)); }
+
+}  // namespace
+
+extern "C" {
+
+size_t agan_bn_stats_ws_bytes(int B, int C, int HW) {
+    if (HW == 1) return 0;
+    return (size_t)C * stats_chunks(B, C, HW) * 2 * sizeof(double);
+}
+
+int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, float* invstd, float* running_mean,
+                  float* running_var, int64_t* nbt, float momentum, void* ws, size_t ws_bytes, void* stream) {
+    AGAN_REQUIRE(x && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_stats: bad argument");
+    AGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running_mean/var must come together");
+    hipStream_t st = as_stream(stream);
+    if (HW == 1) {
+        hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, B, C, eps, mean, invstd, running_mean,
+                           running_var, nbt, momentum);
+        return check_launch("bn_stats_rows");
+    }
+    const int nchunk = stats_chunks(B, C, HW);
+    if (ws_bytes < agan_bn_stats_ws_bytes(B, C, HW) || !ws) {
+        set_error("bn_stats: workspace too small");
+        return AGAN_EWORKSPACE;
+    }
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, nchunk), dim3(256), 0, st, x, B, C, HW, nchunk, part);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, nchunk, B * HW, eps, mean, invstd,
+                       running_mean, running_var, nbt, momentum);
+    return check_launch("bn_stats");
+}
+
+int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    const float* residual, float* out, int B, int C, int HW, int act, void* stream) {
+    AGAN_REQUIRE(x && mean && invstd && gamma && beta && out && B > 0 && C > 0 && HW > 0, "bn_act_fwd: bad argument");
+    AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_fwd: activation %d", act);
+    AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
+    AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_act_fwd: residual only with ACT_NONE");
+    hipStream_t st = as_stream(stream);
+    const bool vec = (HW & 3) == 0;
+    const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
+    const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
+#define AGAN_L(A, V) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW)
+    if (act == AGAN_ACT_GLU) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
+    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
+    else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
+#undef AGAN_L
+    return check_launch("bn_act_fwd");
+}
+
+static int bwd_chunks(int B, int C, int HW) { return stats_chunks(B, C, HW); }
+
+size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW) {
+    return (size_t)C * bwd_chunks(B, C, HW) * 4 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 64;
+}
+
+int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, void* ws,
+                    size_t ws_bytes, void* stream) {
+    AGAN_REQUIRE(x && dout && mean && invstd && gamma && beta && dx && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
+    AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_bwd: activation %d", act);
+    AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
+    if (ws_bytes < agan_bn_act_bwd_ws_bytes(B, C, HW)) {
+        set_error("bn_act_bwd: workspace too small");
+        return AGAN_EWORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const int nchunk = bwd_chunks(B, C, HW);
+    const bool glu = act == AGAN_ACT_GLU;
+    const int Co = glu ? C / 2 : C;
+    double* part = static_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(part + (size_t)C * nchunk * 4);
+    dim3 grid(Co, nchunk);
+    if (glu) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_GLU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
+    else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, B * HW, glu, dgamma, dbeta, coef);
+    const bool vec = (HW & 3) == 0;
+    const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
+#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, coef, dx, B, C, HW)
+    if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
+    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
+    else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
+#undef AGAN_L
+    return check_launch("bn_act_bwd");
+}
+
+int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream) {
+    AGAN_REQUIRE(x && out && n > 0, "act_fwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    const int blocks = ew_blocks(n / 4 + 1);
+    switch (act) {
+        case AGAN_ACT_LRELU: hipLaunchKernelGGL((act_fwd_kernel<AGAN_ACT_LRELU>), dim3(blocks), dim3(256), 0, st, x, out, n); break;
+        case AGAN_ACT_TANH: hipLaunchKernelGGL((act_fwd_kernel<AGAN_ACT_TANH>), dim3(blocks), dim3(256), 0, st, x, out, n); break;
+        case AGAN_ACT_SIGMOID: hipLaunchKernelGGL((act_fwd_kernel<AGAN_ACT_SIGMOID>), dim3(blocks), dim3(256), 0, st, x, out, n); break;
+        default: set_error("act_fwd: activation %d", act); return AGAN_EINVAL;
+    }
+    return check_launch("act_fwd");
+}
+
+int agan_act_bwd(const float* y, const float* dout, float* dx, size_t n, int act, void* stream) {
+    AGAN_REQUIRE(y && dout && dx && n > 0, "act_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    const int blocks = ew_blocks(n / 4 + 1);
+    switch (act) {
+        case AGAN_ACT_LRELU: hipLaunchKernelGGL((act_bwd_kernel<AGAN_ACT_LRELU>), dim3(blocks), dim3(256), 0, st, y, dout, dx, n); break;
+        case AGAN_ACT_TANH: hipLaunchKernelGGL((act_bwd_kernel<AGAN_ACT_TANH>), dim3(blocks), dim3(256), 0, st, y, dout, dx, n); break;
+        case AGAN_ACT_SIGMOID: hipLaunchKernelGGL((act_bwd_kernel<AGAN_ACT_SIGMOID>), dim3(blocks), dim3(256), 0, st, y, dout, dx, n); break;
+        default: set_error("act_bwd: activation %d", act); return AGAN_EINVAL;
+    }
+    return check_launch("act_bwd");
+}
+
+int agan_glu_fwd(const float* x, float* out, int B, int C, int HW, void* stream) {
+    AGAN_REQUIRE(x && out && B > 0 && C > 0 && HW > 0, "glu_fwd: bad argument");
+    AGAN_REQUIRE(C % 2 == 0, "channels dont divide 2!");
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(ew_blocks((size_t)B * (C / 2) * HW)), dim3(256), 0, as_stream(stream), x, out, B, C, HW);
+    return check_launch("glu_fwd");
+}
+
+int agan_glu_bwd(const float* x, const float* dout, float* dx, int B, int C, int HW, void* stream) {
+    AGAN_REQUIRE(x && dout && dx && B > 0 && C > 0 && HW > 0 && C % 2 == 0, "glu_bwd: bad argument");
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_blocks((size_t)B * (C / 2) * HW)), dim3(256), 0, as_stream(stream), x, dout, dx, B, C, HW);
+    return check_launch("glu_bwd");
+}
+
+}  // extern "C"

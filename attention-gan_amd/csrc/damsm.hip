@@ -1,0 +1,455 @@
+// DAMSM losses: WordsLoss.get_loss (losses/words_loss.py:29-102, which loops func_attention networks/attention.py:82-120
+// over the B captions) and SentenceLoss.get_loss (losses/sentence_loss.py:12-50), each as one forward and one backward kernel.
+//
+// words loss: one 320-thread workgroup per (image j, caption i) pair -- B*B workgroups, enough to fill the chip at B=24.
+// Thread r owns image region r (S = 17*17 = 289 <= 320) for everything indexed by region, thread d owns embedding
+// channel d (D <= 320) for everything indexed by channel; the three small matrices they exchange (caption words e[D][T],
+// region attention a2[S][T], weighted context c[D][T]) live in LDS with a +1 pad so both row and column walks are
+// conflict-free.  The backward recomputes the forward of its pair instead of storing B*B*(S*T + D*T) intermediates.
+// Region features are read coalesced along r (NCHW pixel axis) by the region-owning threads.
+#include "agan_common.h"
+
+using namespace agan;
+
+namespace {
+
+constexpr int kNT = 320;      // threads per pair workgroup (5 waves): >= S and >= D
+constexpr int kMaxB = 128;
+
+// Everything the forward of one (image j, caption i) pair produces, left in LDS / registers for the caller.
+template <int TMAX>
+struct PairSmem {
+    float e[kNT][TMAX + 1];    // caption words   e[d][w]  (0 for w >= L)
+    float a2[kNT][TMAX + 1];   // attention       a2[r][w] (softmax over regions of gamma1 * softmax over words)
+    float c[kNT][TMAX + 1];    // weighted context c[d][w]
+    float num[TMAX], n1[TMAX], n2[TMAX], cosv[TMAX];
+    float colmax[TMAX], colsum[TMAX];
+    float red[8];
+};
+
+// Forward of a pair.  On return (after the trailing barrier): sm.e, sm.a2, sm.c, sm.cosv/num/n1/n2 are valid;
+// a1[] holds thread r's first-softmax row (valid for r < S).
+template <int TMAX>
+__device__ __forceinline__ void pair_forward(PairSmem<TMAX>& sm, const float* __restrict__ fj, const float* __restrict__ ei,
+                                             int D, int T, int S, int L, float scale, float gamma1, float eps, float (&a1)[TMAX]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    // 1. caption words into LDS
+    for (int i = tid; i < D * TMAX; i += kNT) {
+        const int d = i / TMAX, w = i - d * TMAX;
+        sm.e[d][w] = w < L ? ei[(size_t)d * T + w] : 0.f;
+    }
+    __syncthreads();
+    // 2. scores for region r = tid, softmax over words (attention.py:99-104)
+    const int r = tid;
+    const bool rlive = r < S;
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) a1[w] = 0.f;
+    if (rlive) {
+        for (int d = 0; d < D; ++d) {
+            const float fv = fj[(size_t)d * S + r];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) a1[w] += fv * sm.e[d][w];
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            a1[w] = w < L ? a1[w] * scale : -INFINITY;
+            mx = fmaxf(mx, a1[w]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            a1[w] = __expf(a1[w] - mx);
+            sum += a1[w];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            a1[w] *= inv;
+            sm.a2[r][w] = a1[w] * gamma1;          // staged for the region softmax (attention.py:111)
+        }
+    }
+    __syncthreads();
+    // 3. softmax over regions, one word column per wave (attention.py:112)
+    for (int w = wave; w < L; w += kNT / 64) {
+        float mx = -INFINITY;
+        for (int q = lane; q < S; q += 64) mx = fmaxf(mx, sm.a2[q][w]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int q = lane; q < S; q += 64) s += __expf(sm.a2[q][w] - mx);
+        s = wave_sum(s);
+        if (lane == 0) { sm.colmax[w] = mx; sm.colsum[w] = s; }
+    }
+    __syncthreads();
+    if (rlive) {
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) sm.a2[r][w] = w < L ? __expf(sm.a2[r][w] - sm.colmax[w]) / sm.colsum[w] : 0.f;
+    }
+    __syncthreads();
+    // 4. weighted context c[d][w] = sum_r f[d][r] a2[r][w]   (attention.py:119), thread d = tid
+    if (tid < D) {
+        float acc[TMAX];
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) acc[w] = 0.f;
+        const float* fr = fj + (size_t)tid * S;
+        for (int q = 0; q < S; ++q) {
+            const float fv = fr[q];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) acc[w] += fv * sm.a2[q][w];
+        }
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) sm.c[tid][w] = acc[w];
+    }
+    __syncthreads();
+    // 5. cosine per word (words_loss.py:20-27,72)
+    for (int w = wave; w < L; w += kNT / 64) {
+        float nu = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float ev = sm.e[d][w], cv = sm.c[d][w];
+            nu += ev * cv; s1 += ev * ev; s2 += cv * cv;
+        }
+        nu = wave_sum(nu); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            const float a = sqrtf(s1), b = sqrtf(s2);
+            sm.num[w] = nu; sm.n1[w] = a; sm.n2[w] = b;
+            sm.cosv[w] = nu / fmaxf(a * b, eps);
+        }
+    }
+    __syncthreads();
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
+                                                             const int64_t* __restrict__ lens, float gamma1, float gamma2, float gamma3,
+                                                             float* __restrict__ sim, float* __restrict__ maps, int B, int D, int T, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    const int j = blockIdx.x, i = blockIdx.y;      // image j, caption i
+    const int L = min((int)lens[i], T);
+    float a1[TMAX];
+    pair_forward<TMAX>(sm, feat + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L, rsqrtf((float)D), gamma1, 1e-8f, a1);
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w]);     // words_loss.py:77-79
+        sim[(size_t)j * B + i] = logf(s) * gamma3;                      // :93
+    }
+    if (i == j && threadIdx.x < S) {                                    // att_maps.append(attn[i]), :63
+        for (int w = 0; w < L; ++w) maps[((size_t)i * T + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
+    }
+}
+
+// Two cross-entropies over a [B][B] similarity matrix with labels = arange, optional same-class mask.
+// Writes loss and dS = d loss / d S (before the upstream gradient).  One workgroup.
+__global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const int64_t* __restrict__ cids, float lambda,
+                                                             float* __restrict__ loss, float* dS, int B) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* S = reinterpret_cast<float*>(smem_raw);      // [B][B]
+    float* rlse = S + B * B;                            // [B] row logsumexp
+    float* clse = rlse + B;                             // [B] column logsumexp
+    __shared__ float red[4];
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        const int r = e / B, c = e - r * B;
+        float v = sim[e];
+        if (cids && r != c && cids[r] == cids[c]) v = -INFINITY;       // words_loss.py:44-47,95
+        S[e] = v;
+        sim[e] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * B; k += 256) {
+        const bool col = k >= B;
+        const int q = col ? k - B : k;
+        float mx = -INFINITY;
+        for (int t = 0; t < B; ++t) mx = fmaxf(mx, col ? S[t * B + q] : S[q * B + t]);
+        float s = 0.f;
+        for (int t = 0; t < B; ++t) s += expf((col ? S[t * B + q] : S[q * B + t]) - mx);
+        (col ? clse : rlse)[q] = mx + logf(s);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int q = threadIdx.x; q < B; q += 256) part += (rlse[q] - S[q * B + q]) + (clse[q] - S[q * B + q]);
+    part = block_sum<256>(part, red);
+    if (threadIdx.x == 0) loss[0] = part / B * lambda;
+    const float sc = lambda / B;
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        const int r = e / B, c = e - r * B;
+        const float v = S[e];
+        float g = 0.f;
+        if (v > -INFINITY) g = expf(v - rlse[r]) + expf(v - clse[c]);
+        if (r == c) g -= 2.f;
+        dS[e] = g * sc;
+    }
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
+                                                             const int64_t* __restrict__ lens, const float* __restrict__ dS,
+                                                             const float* __restrict__ dloss, float gamma1, float gamma2, float gamma3,
+                                                             float* __restrict__ dfeat, float* __restrict__ dwemb, int B, int D, int T, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    __shared__ float dot[TMAX];
+    const int j = blockIdx.x, i = blockIdx.y;
+    const float g = dS[(size_t)j * B + i] * dloss[0] * gamma3;     // d loss / d log-sum-exp of this pair
+    if (g == 0.f) return;                                          // masked pair (uniform across the workgroup)
+    const int L = min((int)lens[i], T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float scale = rsqrtf((float)D), eps = 1e-8f;
+    const float* fj = feat + (size_t)j * D * S;
+    float a1[TMAX];
+    pair_forward<TMAX>(sm, fj, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
+
+    // --- d cos, then d num / d n1 / d n2 per word (uniform, recomputed by every thread from LDS) ---
+    float dnum[TMAX], dn1[TMAX], dn2[TMAX];
+    {
+        float mx = -INFINITY;
+        for (int w = 0; w < L; ++w) mx = fmaxf(mx, gamma2 * sm.cosv[w]);
+        float s = 0.f;
+        for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w] - mx);
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            dnum[w] = dn1[w] = dn2[w] = 0.f;
+            if (w < L) {
+                const float dcos = g * gamma2 * expf(gamma2 * sm.cosv[w] - mx) / s;
+                const float nn = sm.n1[w] * sm.n2[w];
+                if (nn > eps) {
+                    dnum[w] = dcos / nn;
+                    const float k = -dcos * sm.num[w] / (nn * nn);
+                    dn1[w] = k * sm.n2[w];
+                    dn2[w] = k * sm.n1[w];
+                } else {
+                    dnum[w] = dcos / eps;      // clamp(min=eps) active: denominator is a constant
+                }
+            }
+        }
+    }
+    // --- thread d: de (direct part) in registers, dc overwrites c in LDS ---
+    float de[TMAX];
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) de[w] = 0.f;
+    if (tid < D) {
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            const float ev = sm.e[tid][w], cv = sm.c[tid][w];
+            de[w] = dnum[w] * cv + (sm.n1[w] > 0.f ? dn1[w] * ev / sm.n1[w] : 0.f);
+            sm.c[tid][w] = dnum[w] * ev + (sm.n2[w] > 0.f ? dn2[w] * cv / sm.n2[w] : 0.f);
+        }
+    }
+    if (tid < TMAX) dot[tid] = 0.f;
+    __syncthreads();
+    // --- thread r: da2[w] = sum_d f[d][r] dc[d][w];  dot[w] = sum_r a2 da2 ---
+    const int r = tid;
+    const bool rlive = r < S;
+    float a2r[TMAX], da2[TMAX];
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) { da2[w] = 0.f; a2r[w] = rlive ? sm.a2[r][w] : 0.f; }
+    if (rlive) {
+        for (int d = 0; d < D; ++d) {
+            const float fv = fj[(size_t)d * S + r];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) da2[w] += fv * sm.c[d][w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) {
+        const float v = wave_sum(a2r[w] * da2[w]);
+        if (lane == 0 && w < L) atomicAdd(&dot[w], v);
+    }
+    __syncthreads();
+    // softmax-over-regions backward, then softmax-over-words backward -> ds (gradient of the scaled score)
+    float ds[TMAX];
+    {
+        float inner = 0.f;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            ds[w] = gamma1 * a2r[w] * (da2[w] - (w < L ? dot[w] : 0.f));   // = d a1[w]
+            inner += a1[w] * ds[w];
+        }
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) ds[w] = (w < L && rlive) ? a1[w] * (ds[w] - inner) * scale : 0.f;   // d raw score
+    }
+    // --- dfeat[j][d][r] += sum_w dc[d][w] a2[r][w] + ds[r][w] e[d][w]   (coalesced along r) ---
+    if (rlive) {
+        float* dfj = dfeat + (size_t)j * D * S + r;
+        for (int d = 0; d < D; ++d) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) v += sm.c[d][w] * a2r[w] + ds[w] * sm.e[d][w];
+            atomicAdd(dfj + (size_t)d * S, v);
+        }
+    }
+    __syncthreads();                 // everyone is done reading a2 (registers now) -> reuse its storage for ds
+    if (rlive) {
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) sm.a2[r][w] = ds[w];
+    }
+    __syncthreads();
+    // --- thread d: de[d][w] += sum_r ds[r][w] f[d][r];  dwemb[i][d][w] += de ---
+    if (tid < D) {
+        const float* fr = fj + (size_t)tid * S;
+        for (int q = 0; q < S; ++q) {
+            const float fv = fr[q];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) de[w] += fv * sm.a2[q][w];
+        }
+        float* dwi = dwemb + ((size_t)i * D + tid) * T;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w)
+            if (w < L) atomicAdd(dwi + w, de[w]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sentence loss (one workgroup)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sent_scores_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn, float gamma3,
+                                                          float eps, float* __restrict__ sim, float* __restrict__ dots,
+                                                          float* __restrict__ norms, int B, int D) {
+    // norms[0..B) = |cnn_j|, norms[B..2B) = |rnn_i|; dots[j][i] = <cnn_j, rnn_i>; sim = gamma3 * dots / max(nc*nr, eps)
+    __shared__ float nc[kMaxB], nr[kMaxB];
+    for (int k = threadIdx.x; k < 2 * B; k += 256) {
+        const float* p = (k < B ? cnn + (size_t)k * D : rnn + (size_t)(k - B) * D);
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += p[d] * p[d];
+        s = sqrtf(s);
+        (k < B ? nc[k] : nr[k - B]) = s;
+        norms[k] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        const int j = e / B, i = e - j * B;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += cnn[(size_t)j * D + d] * rnn[(size_t)i * D + d];
+        dots[e] = s;
+        sim[e] = s / fmaxf(nc[j] * nr[i], eps) * gamma3;      // sentence_loss.py:33-38
+    }
+}
+
+__global__ __launch_bounds__(256) void sent_bwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn, const float* __restrict__ dS,
+                                                       const float* __restrict__ dots, const float* __restrict__ norms,
+                                                       const float* __restrict__ dloss, float gamma3, float eps, float* __restrict__ dcnn,
+                                                       float* __restrict__ drnn, int B, int D) {
+    const float up = dloss[0] * gamma3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * B * D; e += gridDim.x * 256) {
+        const bool isr = e >= B * D;
+        const int q = isr ? e - B * D : e;
+        const int a = q / D, d = q - a * D;            // a = own row (image j for cnn, caption i for rnn)
+        float acc = 0.f;
+        for (int o = 0; o < B; ++o) {
+            const int j = isr ? o : a, i = isr ? a : o;
+            const float gji = dS[j * B + i] * up;
+            const float nc = norms[j], nr = norms[B + i], nn = nc * nr;
+            const float other = isr ? cnn[(size_t)j * D + d] : rnn[(size_t)i * D + d];
+            const float self = isr ? rnn[(size_t)i * D + d] : cnn[(size_t)j * D + d];
+            if (nn > eps) {
+                const float ns = isr ? nr : nc, no = isr ? nc : nr;
+                acc += gji * (other / nn - dots[j * B + i] / (nn * nn) * no * (ns > 0.f ? self / ns : 0.f));
+            } else {
+                acc += gji * other / eps;
+            }
+        }
+        (isr ? drnn : dcnn)[q] = acc;
+    }
+}
+
+// standalone func_attention forward (networks/attention.py:82-120): query [B,D,L], context [B,D,S] -> wctx [B,D,L], attn [B,L,S]
+template <int TMAX>
+__global__ __launch_bounds__(kNT) void func_attn_fwd_kernel(const float* __restrict__ query, const float* __restrict__ context, float gamma1,
+                                                            float scale, float* __restrict__ wctx, float* __restrict__ attn, int D, int L, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    const int b = blockIdx.x;
+    float a1[TMAX];
+    pair_forward<TMAX>(sm, context + (size_t)b * D * S, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
+    if (threadIdx.x < D)
+        for (int w = 0; w < L; ++w) wctx[((size_t)b * D + threadIdx.x) * L + w] = sm.c[threadIdx.x][w];
+    if (threadIdx.x < S)
+        for (int w = 0; w < L; ++w) attn[((size_t)b * L + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
+}
+
+template <int TMAX>
+constexpr size_t pair_smem_bytes() { return sizeof(PairSmem<TMAX>); }
+
+}  // namespace
+
+extern "C" {
+
+size_t agan_words_loss_save_elems(int B, int D, int T, int S) { return (size_t)B * B; }
+
+int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, float gamma1,
+                        float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps, float* save, int B,
+                        int D, int T, int S, void* stream) {
+    AGAN_REQUIRE(feat && wemb && lens && loss && sim && attn_maps && save, "words_loss_fwd: null pointer");
+    AGAN_REQUIRE(B >= 1 && B <= kMaxB, "words_loss: batch %d out of range [1,%d]", B, kMaxB);
+    AGAN_REQUIRE(D >= 1 && D <= kNT && S >= 1 && S <= kNT, "words_loss: nef %d / regions %d exceed %d", D, S, kNT);
+    AGAN_REQUIRE(T >= 1 && T <= 32, "words_loss: seq_len %d > 32", T);
+    hipStream_t st = as_stream(stream);
+    dim3 grid(B, B);
+    if (T <= 16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        hipLaunchKernelGGL((words_pair_fwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        hipLaunchKernelGGL((words_pair_fwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
+    }
+    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, lambda, loss, save, B);
+    return check_launch("words_loss_fwd");
+}
+
+int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* lens, const float* save, const float* dloss, float gamma1,
+                        float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb, int B, int D, int T, int S, void* stream) {
+    AGAN_REQUIRE(feat && wemb && lens && save && dloss && dfeat && dwemb, "words_loss_bwd: null pointer");
+    AGAN_REQUIRE(B >= 1 && B <= kMaxB && D <= kNT && S <= kNT && T <= 32, "words_loss_bwd: shape out of range");
+    hipStream_t st = as_stream(stream);
+    dim3 grid(B, B);     // dfeat / dwemb must be zero-initialised by the caller (they are accumulated with atomics)
+    if (T <= 16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        hipLaunchKernelGGL((words_pair_bwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        hipLaunchKernelGGL((words_pair_bwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
+    }
+    return check_launch("words_loss_bwd");
+}
+
+int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, float gamma3, float lambda, float eps,
+                       float* loss, float* save, int B, int D, void* stream) {
+    AGAN_REQUIRE(cnn_code && rnn_code && loss && save, "sent_loss_fwd: null pointer");
+    AGAN_REQUIRE(B >= 1 && B <= kMaxB && D >= 1, "sent_loss: batch %d out of range", B);
+    hipStream_t st = as_stream(stream);
+    float* dS = save;                 // [B*B]  d loss / d sim
+    float* dots = save + B * B;       // [B*B]
+    float* norms = dots + B * B;      // [2B]
+    // sim is staged in dS's storage, then overwritten by the CE kernel's gradient
+    hipLaunchKernelGGL(sent_scores_kernel, dim3(1), dim3(256), 0, st, cnn_code, rnn_code, gamma3, eps, dS, dots, norms, B, D);
+    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, dS, class_ids, lambda, loss, dS, B);
+    return check_launch("sent_loss_fwd");
+}
+
+int agan_sent_loss_bwd(const float* cnn_code, const float* rnn_code, const float* save, const float* dloss, float gamma3, float lambda,
+                       float eps, float* dcnn, float* drnn, int B, int D, void* stream) {
+    AGAN_REQUIRE(cnn_code && rnn_code && save && dloss && dcnn && drnn, "sent_loss_bwd: null pointer");
+    const float* dS = save;
+    const float* dots = save + B * B;
+    const float* norms = dots + B * B;
+    hipLaunchKernelGGL(sent_bwd_kernel, dim3(cdiv(2 * B * D, 256)), dim3(256), 0, as_stream(stream), cnn_code, rnn_code, dS, dots, norms,
+                       dloss, gamma3, eps, dcnn, drnn, B, D);
+    return check_launch("sent_loss_bwd");
+}
+
+int agan_func_attention_fwd(const float* query, const float* context, float gamma1, float scale, float* wctx, float* attn, int B,
+                            int D, int L, int S, void* stream) {
+    AGAN_REQUIRE(query && context && wctx && attn, "func_attention_fwd: null pointer");
+    AGAN_REQUIRE(B >= 1 && D >= 1 && D <= kNT && S >= 1 && S <= kNT && L >= 1 && L <= 32, "func_attention: shape out of range");
+    hipStream_t st = as_stream(stream);
+    if (L <= 16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        hipLaunchKernelGGL((func_attn_fwd_kernel<16>), dim3(B), dim3(kNT), pair_smem_bytes<16>(), st, query, context, gamma1, scale, wctx, attn, D, L, S);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        hipLaunchKernelGGL((func_attn_fwd_kernel<32>), dim3(B), dim3(kNT), pair_smem_bytes<32>(), st, query, context, gamma1, scale, wctx, attn, D, L, S);
+    }
+    return check_launch("func_attention_fwd");
+}
+
+}  // extern "C"

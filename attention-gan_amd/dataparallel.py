@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).
+
+New component (the reference is single-GPU).  Every replica keeps BatchNorm statistics and the
+DAMSM B x B matrix local, exactly as the reference computes them per batch; the only exchange is a SUM all-reduce of
+weight gradients, issued per bucket on a side stream as soon as backward has produced every gradient of the bucket,
+and joined right before that optimiser's step (which applies the 1/world_size scale inside the fused Adam kernel).
+
+Buckets are contiguous slices of FlatAdam's flat gradient buffer, so a bucket is one large RCCL call; xGMI is
+point-to-point (7 links x ~153 GB/s per GPU), so few large messages beat many small ones.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import FlatAdam
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Identical initial weights and BN buffers on every replica."""
+    if world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class GradBuckets:
+    """Bucketed, backward-overlapped all-reduce over a FlatAdam's flat gradient buffer."""
+
+    def __init__(self, opt: FlatAdam, bucket_bytes: int = 64 << 20, group=None):
+        self.opt, self.group = opt, group
+        self.world = world_size(group)
+        self.bounds: List[tuple] = []          # (start, end) element ranges of the flat gradient buffer
+        self.param_bucket: List[int] = []
+        per = max(1, bucket_bytes // 4)
+        start, b = 0, 0
+        for p, o in zip(opt.params, opt.offsets):
+            end = o + (p.numel() + 3) // 4 * 4
+            if end - start > per and o > start:
+                self.bounds.append((start, o))
+                start, b = o, b + 1
+            self.param_bucket.append(b)
+        self.bounds.append((start, opt.numel))
+        self.counts = [self.param_bucket.count(i) for i in range(len(self.bounds))]
+        self._pending = list(self.counts)
+        self._handles: List = []
+        self._armed = False
+        self.comm_stream: Optional[torch.cuda.Stream] = None
+        if self.world > 1:
+            if opt.flat.is_cuda:
+                self.comm_stream = torch.cuda.Stream(device=opt.flat.device)
+            for i, p in enumerate(opt.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def arm(self) -> None:
+        """Call before the backward whose gradients should be exchanged (after zero_grad)."""
+        self._pending = list(self.counts)
+        self._handles = []
+        self._armed = True
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            if not self._armed:
+                return
+            b = self.param_bucket[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        s, e = self.bounds[b]
+        self.opt._rebind()
+        chunk = self.opt.grad[s:e]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> float:
+        """Join outstanding exchanges; returns the scale the optimiser must apply (1/world_size)."""
+        if self.world == 1:
+            return 1.0
+        # buckets whose parameters received no gradient this backward (unused params) are reduced too so that
+        # every rank issues the same collectives
+        for b, left in enumerate(self._pending):
+            if self._armed and left > 0:
+                self._pending[b] = 0
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._handles, self._armed = [], False
+        return 1.0 / self.world

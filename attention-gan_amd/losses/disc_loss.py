@@ -1,0 +1,35 @@
+"""Discriminator losses with the reference's interface (losses/disc_loss.py)."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from ..backend import functional as HF
+
+
+class DiscLoss:
+    def make_labels_for_real_imgs(self, num_labels: int, label_smooth=0.8, device="cuda") -> Tensor:
+        return torch.empty(num_labels, device=device).uniform_(label_smooth, 1.0)
+
+    def make_labels_for_fake_imgs(self, num_labels: int, device="cuda") -> Tensor:
+        return torch.zeros(num_labels, device=device)
+
+    def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
+        raise NotImplementedError
+
+
+class NonSaturatingDiscLoss(DiscLoss):
+    """-mean(log(D(x)+1e-8) + log(1-D(G(z))+1e-8)); the real batch goes through D first (disc_loss.py:55-61)."""
+
+    def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
+        dx_score = discriminator(real_images)
+        dg_score = discriminator(fake_images)
+        return HF.ns_disc_loss(dx_score, dg_score)
+
+
+class StandardDiscLoss(DiscLoss):
+    """BCE variant (disc_loss.py:26-47); not used by train.py:74-75 -- kept for API completeness, not a HIP kernel."""
+
+    def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
+        raise NotImplementedError("StandardDiscLoss is outside the AttnGAN hot path (train.py:75 uses NonSaturatingDiscLoss)")

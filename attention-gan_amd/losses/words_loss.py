@@ -1,0 +1,35 @@
+"""DAMSM word-level loss with the reference's interface (losses/words_loss.py), one fused HIP kernel pair."""
+from __future__ import annotations
+
+import torch
+
+from ..backend import functional as HF
+
+
+class WordsLoss:
+    """Same constructor and `get_loss` contract as the reference (words_loss.py:13-18, 29-102).
+
+    The reference loops `func_attention` over the B captions in Python (~25 tiny kernels each); here all
+    B x B (image, caption) pairs are evaluated by one kernel and back-propagated by another.
+    """
+
+    def __init__(self, device: torch.device, gamma1=4.0, gamma2=5.0, gamma3=10.0, wlambda=5.0):
+        self.device = device
+        self.gamma1, self.gamma2, self.gamma3, self.wlambda = gamma1, gamma2, gamma3, wlambda
+
+    def cosine_similarity(self, x1, x2, dim=1, eps=1e-8):
+        w12 = torch.sum(x1 * x2, dim)
+        return (w12 / (torch.norm(x1, 2, dim) * torch.norm(x2, 2, dim)).clamp(min=eps)).squeeze()
+
+    def get_loss(self, img_features, words_emb, labels, cap_lens, class_ids):
+        """img_features [B,nef,17,17], words_emb [B,nef,T], labels [B] (= arange, as train.py:104 builds them),
+        cap_lens [B], class_ids [B] array or None -> (loss, [attention map [1,L_i,17,17] per caption])."""
+        b = img_features.shape[0]
+        lens = [int(v) for v in (cap_lens.tolist() if hasattr(cap_lens, "tolist") else cap_lens)]
+        if labels is not None and labels.numel() != b:
+            raise ValueError("labels must have one entry per sample")
+        loss, maps, _ = HF.words_loss(img_features, words_emb, lens, class_ids, self.gamma1, self.gamma2, self.gamma3,
+                                      self.wlambda)
+        ih, iw = img_features.shape[2], img_features.shape[3]
+        att_maps = [maps[i:i + 1, :lens[i]].reshape(1, lens[i], ih, iw) for i in range(b)]
+        return (loss, att_maps)

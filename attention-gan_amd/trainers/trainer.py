@@ -1,0 +1,185 @@
+"""`ModelTrainer` helpers with the reference's names (trainers/trainer.py:13-127) and the GAN train step of
+train.py:109-151 as a reusable object (`GanTrainStep`) with flat-buffer Adam and overlapped gradient all-reduce."""
+from __future__ import annotations
+
+import math
+import os
+from datetime import datetime
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from ..dataparallel import GradBuckets, broadcast_module_, world_size
+from ..losses.disc_loss import NonSaturatingDiscLoss
+from ..losses.gen_loss import NonSaturatingGenLoss
+from ..losses.KL_loss import KL_loss
+from ..losses.sentence_loss import SentenceLoss
+from ..losses.words_loss import WordsLoss
+from ..optim import FlatAdam
+
+
+def _device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+class ModelTrainer:
+    """Label / noise / denormalise / checkpoint helpers (reference trainer.py:20-43,109-127)."""
+
+    def __init__(self):
+        pass
+
+    def _make_match_labels(self, batch_size: int) -> Tensor:
+        return torch.arange(batch_size, dtype=torch.int64, device=_device())
+
+    def _count_parameters(self, model: Module):
+        n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        print(f"Model {model.__class__.__name__} has {n} parameters")
+        return n
+
+    def _make_noise(self, batch_size: int, z_dim: int) -> Tensor:
+        return torch.randn(batch_size, z_dim, dtype=torch.float32, device=_device())
+
+    def _make_mask(self, lengths) -> Tensor:
+        """[[1]*len + [0]*(max-len)] int64 (train.py:96-100)."""
+        lens = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+        mx = max(lens)
+        return torch.tensor([[1] * l + [0] * (mx - l) for l in lens], dtype=torch.int64, device=_device())
+
+    def _denormalise_single(self, tensor: Tensor) -> Tensor:
+        return tensor * 0.5 + 0.5
+
+    def _denormalise_multiple(self, tensors: List[Tensor]) -> List[Tensor]:
+        return [self._denormalise_single(t) for t in tensors]
+
+    def _plot_history(self, history, epoch=None, window_size=100, name='loss_hist', folder='generated_images') -> None:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        for h in ([history] if not isinstance(history[0], list) else history):
+            avg = [sum(h[i:i + window_size]) / window_size for i in range(max(0, len(h) - window_size + 1))]
+            plt.plot(avg)
+        os.makedirs(folder, exist_ok=True)
+        plt.savefig(f"{folder}/epoch_{epoch}-{name}")
+        plt.close()
+
+    def _plot_image_grid(self, fake_images: List[Tensor], epoch: int = None, folder='generated_images') -> None:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        n = len(fake_images[0])
+        side = int(math.isqrt(n))
+        os.makedirs(folder, exist_ok=True)
+        for images in fake_images:
+            res = images.shape[-1]
+            imgs = images[:side * side].detach().cpu()
+            f, ax = plt.subplots(side, side, squeeze=False)
+            for k in range(side * side):
+                a = ax[k // side][k % side]
+                a.axis('off')
+                a.imshow(imgs[k].permute(1, 2, 0).clamp(0, 1))
+            stamp = str(datetime.now()).split('.')[0].replace(':', '-')
+            plt.savefig(f'{folder}/epoch_{epoch}-{res}x{res}.png' if epoch else f'{folder}/_{res}x{res}-{stamp}.png')
+            plt.close()
+
+    def _save_weights(self, modules: List, root_folder='saved_weights') -> None:
+        """state_dict per module at {root}/{ClassName}.pkl.  Optimisers get an index suffix so that the reference's
+        four `Adam` objects no longer overwrite one Adam.pkl (SURVEY.md §5 checkpoint note)."""
+        os.makedirs(root_folder, exist_ok=True)
+        seen: Dict[str, int] = {}
+        for m in modules:
+            name = m.__class__.__name__
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            path = f"{root_folder}/{name}.pkl" if k == 0 else f"{root_folder}/{name}_{k}.pkl"
+            torch.save(m.state_dict(), path)
+            print(f'Module {name} weights saved to {path}')
+
+    def _load_weights(self, modules: List[Module], root_folder='saved_weights') -> None:
+        for m in modules:
+            name = m.__class__.__name__
+            path = f"{root_folder}/{name}.pkl"
+            try:
+                m.load_state_dict(torch.load(path, weights_only=True))
+                m.eval()
+                print(f'Module {name} weights loaded from {path}')
+            except FileNotFoundError:
+                print(f'FAILED: Module {name}... weights at path {path} were not found')
+
+
+class GanTrainStep(ModelTrainer):
+    """One batch of GanTrainer.train_gan (train.py:109-151): three discriminator updates, then one generator update.
+
+    Results-identical departures from the script: fakes are detached in the D updates (the reference back-props
+    through G there and discards the result at :132); D weight gradients are not produced in the G update.
+    BatchNorm call order per D is kept: real batch, fake batch (D update), fake batch again (G update).
+    """
+
+    def __init__(self, generator: Module, discriminators: Sequence[Module], image_encoder: Optional[Callable] = None,
+                 gen_lr: float = 2e-4, disc_lr: float = 2e-4, gamma1: float = 4.0, gamma2: float = 5.0, gamma3: float = 10.0,
+                 wlambda: float = 5.0, slambda: float = 5.0, bucket_bytes: int = 64 << 20, group=None):
+        super().__init__()
+        self.G, self.Ds, self.image_encoder = generator, list(discriminators), image_encoder
+        self.group = group
+        for m in [self.G] + self.Ds:
+            broadcast_module_(m, 0, group)
+        self.g_opt = FlatAdam(self.G.parameters(), lr=gen_lr, betas=(0.5, 0.999))
+        self.d_opts = [FlatAdam(d.parameters(), lr=disc_lr, betas=(0.5, 0.999)) for d in self.Ds]
+        self.g_buckets = GradBuckets(self.g_opt, bucket_bytes, group)
+        self.d_buckets = [GradBuckets(o, bucket_bytes, group) for o in self.d_opts]
+        dev = next(self.G.parameters()).device
+        self.words_loss = WordsLoss(dev, gamma1, gamma2, gamma3, wlambda)
+        self.sent_loss = SentenceLoss(dev, gamma3, slambda)
+        self.disc_loss, self.gen_loss = NonSaturatingDiscLoss(), NonSaturatingGenLoss()
+        self.g_losses: List = []
+        self.d_losses: List = []
+        self.damsm_losses: List = []
+
+    def step(self, word_embs: Tensor, sent_embs: Tensor, lengths, class_ids, real_imgs: Sequence[Tensor],
+             noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        b = word_embs.shape[0]
+        labels = self._make_match_labels(b)
+        mask = self._make_mask(lengths)
+        if noise is None:
+            noise = self._make_noise(b, self.G.z_dim)
+        fakes, _attn, mu, logvar = self.G(noise, sent_embs, word_embs, mask, eps)
+        out: Dict[str, Tensor] = {}
+        # ---- discriminator updates (train.py:123-130) ----
+        for i, (d, opt, bk) in enumerate(zip(self.Ds, self.d_opts, self.d_buckets)):
+            opt.zero_grad()
+            bk.arm()
+            loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
+            loss.backward()
+            opt.step(bk.finish())
+            out[f"d_loss{i}"] = loss.detach()
+        # ---- generator update (train.py:132-151) ----
+        self.g_opt.zero_grad()
+        self.g_buckets.arm()
+        for d in self.Ds:
+            d.requires_grad_(False)
+        total = None
+        for i, d in enumerate(self.Ds):
+            gl = self.gen_loss.get_loss(d, fakes[i])
+            total = gl if total is None else total + gl
+            out[f"g_loss{i}"] = gl.detach()
+            if i == len(self.Ds) - 1 and self.image_encoder is not None:
+                regions, code = self.image_encoder(fakes[i])
+                wl, _ = self.words_loss.get_loss(regions, word_embs, labels, lengths, class_ids)
+                sl = self.sent_loss.get_loss(code, sent_embs, labels, class_ids)
+                total = total + wl + sl
+                out["w_loss"], out["s_loss"] = wl.detach(), sl.detach()
+        kl = KL_loss(mu, logvar)
+        total = total + kl
+        out["kl"], out["g_total"] = kl.detach(), total.detach()
+        total.backward()
+        for d in self.Ds:
+            d.requires_grad_(True)
+        self.g_opt.step(self.g_buckets.finish())
+        # loss histories stay device tensors: no .item() host sync inside the step (reference syncs at train.py:130,144-145)
+        self.d_losses.append(out[f"d_loss{len(self.Ds) - 1}"])
+        self.g_losses.append(out[f"g_loss{len(self.Ds) - 1}"])
+        if "w_loss" in out:
+            self.damsm_losses.append(out["w_loss"] + out["s_loss"])
+        out["fake_imgs"] = [f.detach() for f in fakes]
+        return out

@@ -1,0 +1,192 @@
+/*
+ * agan.h -- C ABI of libagan_hip.so, the MI355X (gfx950) kernels under the AttnGAN training hot path.
+ *
+ * The reference (ku222/Attention-GAN) is pure Python on PyTorch and has no FFI of its own
+ * (SURVEY.md §8b); its boundary is the Python module surface (networks/, losses/, utilities/layers.py,
+ * trainers/trainer.py).  This header is the layer directly underneath that surface: each entry point
+ * names the reference call site whose ATen ops it replaces.  The Python host code in
+ * attention-gan_amd/ binds these with ctypes from torch.autograd.Function.forward/backward
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned, contiguous, 16-byte-aligned storage
+ *     (NCHW fp32 unless stated); the library never allocates, frees, synchronises or keeps state;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*), so it is graph-capturable;
+ *   - return value 0 = ok, negative AGAN_E* otherwise; agan_last_error() gives the message (thread-local);
+ *   - "ws" is scratch the caller provides; the *_ws_bytes() function of an op says how much it needs.
+ */
+#ifndef AGAN_H_
+#define AGAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGAN_VERSION 100 /* 0.1.0 */
+
+enum {
+    AGAN_OK = 0,
+    AGAN_EINVAL = -1,    /* bad argument / unsupported shape */
+    AGAN_EWORKSPACE = -2,/* workspace too small */
+    AGAN_ELAUNCH = -3    /* HIP launch failure */
+};
+
+/* arithmetic mode of the MFMA contractions (fp32 storage everywhere, fp32 accumulate always) */
+enum {
+    AGAN_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity mode)             */
+    AGAN_PREC_BF16 = 1,  /* operands rounded to bf16 when staged, v_mfma_f32_32x32x16_bf16        */
+    AGAN_PREC_BF16X3 = 2 /* bf16 hi/lo split, 3 MFMAs per product: ~fp32 accuracy at bf16 MFMA rate */
+};
+
+int agan_version(void);
+const char* agan_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gather-convolution geometry.  One descriptor covers every convolution on the path:
+ *
+ *   out[b, n, y'*OS+py, x'*OS+px] = sum_{c<Cin, r<R, s<S}
+ *         in[b, c, y'*SY + r*DY + OY[py], x'*SY + s*DY + OY[px]] * wk[py*OS+px][(c*R + r)*S + s][n]
+ *
+ * (taps outside [0,IH)x[0,IW) read zero).  OS = 1 is an ordinary strided conv; OS = 2 splits the output
+ * into its 4 parity classes, each with its own RxS taps -- which is how a stride-2 transposed conv and a
+ * conv over a nearest-x2-upsampled input are expressed WITHOUT zero-insertion / without materialising the
+ * upsampled tensor (K3 in SURVEY.md §2.1 never exists in HBM, and costs 4/9 of the 3x3 MACs).
+ *
+ * wk is the packed weight  [OS*OS][K = Cin*R*S][Nld],  Nld = agan_round_up(Cout, 32), zero padded,
+ * produced from the reference's OIHW parameter by agan_pack_weight().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct agan_conv_geom {
+    int32_t B;
+    int32_t Cin, IH, IW;   /* gathered tensor  [B, Cin, IH, IW]  */
+    int32_t Cout, OH, OW;  /* produced tensor  [B, Cout, OH, OW] */
+    int32_t R, S;          /* taps per class                      */
+    int32_t OS;            /* 1 or 2                              */
+    int32_t SY, DY;        /* input step per output-lattice step / per tap (same in y and x) */
+    int32_t OY[2];         /* input offset for output parity 0 / 1 */
+} agan_conv_geom;
+
+/* how agan_pack_weight lays an OIHW tensor out for a given use */
+enum {
+    AGAN_PACK_FWD = 0,       /* conv KHxKW any stride (layers.py:50-53,122):  wk[(ci,r,s)][co] = w[co][ci][r][s]            */
+    AGAN_PACK_DGRAD_S1 = 1,  /* dgrad of a stride-1 'same' conv: wk[(co,r,s)][ci] = w[co][ci][KH-1-r][KW-1-s]              */
+    AGAN_PACK_DGRAD_4x4S2 = 2,/* dgrad of conv4x4 s2 p1 as 4 parity classes of 2x2 taps                                     */
+    AGAN_PACK_UP_FWD = 3,    /* Upsample(x2 nearest)+conv3x3 (layers.py:64-65) folded into 4 parity classes of 2x2 taps    */
+    AGAN_PACK_UP_DGRAD = 4   /* its dgrad folded into one 4x4 stride-2 conv over dY                                         */
+};
+
+size_t agan_packed_weight_elems(int mode, int cout, int cin, int kh, int kw);
+/* w: OIHW [cout][cin][kh][kw] -> wk (see modes).  Replaces nothing in the reference: layout prep for the kernels below. */
+int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int kh, int kw, void* stream);
+
+/* conv forward / dgrad: replaces F.conv2d fwd+dgrad under Layers.conv3x3 / conv4x4 s2 / Upsample+conv3x3 /
+ * nn.Linear (1x1 on a 1x1 image) -- utilities/layers.py:50-53,64-65,122,139-150; generator_submodules.py:36,152;
+ * discriminators.py:15.   bias may be NULL. */
+size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g);
+int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* g,
+                     int prec, void* ws, size_t ws_bytes, void* stream);
+
+/* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.
+ * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).
+ * Replaces the wgrad half of conv2d backward at the same call sites. */
+size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
+int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, int pack_mode, int kh, int kw,
+                    int prec, void* ws, size_t ws_bytes, void* stream);
+
+/* dbias[n] = sum_{b,y,x} dy[b,n,y,x]  (bias of nn.Linear / outlogits conv: generator_submodules.py:152, discriminators.py:15) */
+int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm + activation (utilities/layers.py:66-67,123-124,143-144,164-174; generator_submodules.py:38)
+ * ---------------------------------------------------------------------------------------------- */
+enum { AGAN_ACT_NONE = 0, AGAN_ACT_GLU = 1, AGAN_ACT_LRELU = 2, AGAN_ACT_TANH = 3, AGAN_ACT_SIGMOID = 4 };
+
+/* batch statistics over (B, HW) per channel: mean[C], invstd[C] = 1/sqrt(biased var + eps).  If running_mean is
+ * non-NULL also does running = (1-momentum)*running + momentum*stat (unbiased var) and ++*num_batches_tracked. */
+size_t agan_bn_stats_ws_bytes(int B, int C, int HW);
+int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, float* invstd,
+                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                  void* ws, size_t ws_bytes, void* stream);
+/* y = act(gamma*(x-mean)*invstd+beta) [+ residual].  GLU halves the channels (out has C/2).  residual may be NULL. */
+int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    const float* residual, float* out, int B, int C, int HW, int act, void* stream);
+/* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU). */
+size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
+int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act,
+                    void* ws, size_t ws_bytes, void* stream);
+/* plain activations without BN (first D conv + LeakyReLU layers.py:139-140; tanh generator_submodules.py:137) */
+int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream);
+int agan_act_bwd(const float* out, const float* dout, float* dx, size_t n, int act, void* stream);
+/* standalone GLU over channel halves of [B,C,HW] (utilities/layers.py:13-26; the CA-net's "relu", generator_submodules.py:153) */
+int agan_glu_fwd(const float* x, float* out, int B, int C, int HW, void* stream);
+int agan_glu_bwd(const float* x, const float* dout, float* dx, int B, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Word-context attention: AttentionModule.forward, networks/attention.py:25-79
+ *   proj[b,c,t] = sum_e w[c,e] words[b,e,t]                      (:50-52, conv1x1)
+ *   attn[b,t,p] = softmax_t( scale * sum_c images[b,c,p] proj[b,c,t], mask[b,t]==0 -> -inf )   (:59-68)
+ *   ctx[b,c,p]  = sum_t proj[b,c,t] attn[b,t,p]                 (:73)
+ * T <= 64.  mask is the reference's int64 [B,T].
+ * ---------------------------------------------------------------------------------------------- */
+int agan_attn_fwd(const float* images, const float* words, const float* w, const int64_t* mask, float scale,
+                  float* proj, float* ctx, float* attn, int B, int C, int E, int T, int HW, void* stream);
+/* dctx / dattn may be NULL (treated as zero).  Outputs dimages[B,C,HW], dwords[B,E,T], dw[C,E].  ws: B*C*T floats. */
+size_t agan_attn_bwd_ws_bytes(int B, int C, int T);
+int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
+                  const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw,
+                  int B, int C, int E, int T, int HW, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DAMSM losses: WordsLoss.get_loss (losses/words_loss.py:29-102, which loops func_attention
+ * networks/attention.py:82-120 over captions) and SentenceLoss.get_loss (losses/sentence_loss.py:12-50).
+ *   feat [B,D,S] image regions, wemb [B,D,T] words, lens[B] int64, class_ids[B] int64 or NULL.
+ * Outputs: loss[1]; sim[B*B] (gamma3-scaled, masked similarity matrix: [image][caption]); attn maps
+ * [B(caption)][T][S] of each caption against ITS OWN image (what the reference returns in att_maps).
+ * fwd also leaves everything the backward needs in `save` (agan_words_loss_save_elems floats).
+ * ---------------------------------------------------------------------------------------------- */
+/* standalone func_attention forward (attention.py:82-120): query [B,D,L], context [B,D,S] -> wctx [B,D,L], attn [B,L,S] */
+int agan_func_attention_fwd(const float* query, const float* context, float gamma1, float scale, float* wctx, float* attn,
+                            int B, int D, int L, int S, void* stream);
+size_t agan_words_loss_save_elems(int B, int D, int T, int S);
+int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids,
+                        float gamma1, float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps,
+                        float* save, int B, int D, int T, int S, void* stream);
+int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* lens, const float* save, const float* dloss,
+                        float gamma1, float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb,
+                        int B, int D, int T, int S, void* stream);
+int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, float gamma3, float lambda,
+                       float eps, float* loss, float* save /* 2*B*B + 2*B floats */, int B, int D, void* stream);
+int agan_sent_loss_bwd(const float* cnn_code, const float* rnn_code, const float* save, const float* dloss, float gamma3,
+                       float lambda, float eps, float* dcnn, float* drnn, int B, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small fused heads: GAN / KL losses and the CA-net reparametrisation
+ *   disc: -mean(log(pr+1e-8)+log(1-pf+1e-8))  losses/disc_loss.py:55-61   (pr = D(x), pf = D(G(z)): probabilities)
+ *   gen : -mean(log(pf+1e-8))                 losses/gen_loss.py:45-46
+ *   kl  : -0.5*mean(1+lv-mu^2-exp(lv))        losses/KL_loss.py:5-9
+ *   reparam: c = eps*exp(0.5*lv)+mu           networks/generator_submodules.py:161-165
+ * Each loss kernel also writes d(loss)/d(input) (pointers may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int agan_disc_loss(const float* p_real, const float* p_fake, float* loss, float* dp_real, float* dp_fake, int B, void* stream);
+int agan_gen_loss(const float* p_fake, float* loss, float* dp_fake, int B, void* stream);
+int agan_kl_loss(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, int n, void* stream);
+int agan_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* c, int n, void* stream);
+int agan_reparam_bwd(const float* logvar, const float* eps, const float* dc, float* dmu, float* dlogvar, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused Adam over one flat parameter buffer (torch.optim.Adam as configured at train.py:78-80:
+ * no weight decay, no amsgrad).  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+ * ---------------------------------------------------------------------------------------------- */
+int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, double lr,
+                   double beta1, double beta2, double eps, float grad_scale, void* stream);
+
+/* utility used by the host: out = sum of nsplit slabs of n floats (+bias per channel if given) */
+static inline int agan_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGAN_H_ */
