@@ -125,11 +125,24 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     return wk
 
 
-def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor) -> None:
+# optional launch observer (bench.py times the conv engine with HIP events through it): begin(kind, phase, geom) / end()
+_OBSERVER = [None]
+
+
+def set_launch_observer(obs) -> None:
+    _OBSERVER[0] = obs
+
+
+def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "") -> None:
     lib = L.load()
     nbytes = lib.agan_conv_gather_ws_bytes(byref(g))
     ws, wsp = _ws(nbytes, x)
+    obs = _OBSERVER[0]
+    if obs is not None:
+        obs.begin(kind, phase, g)
     L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _PRECISION[0], wsp, nbytes, _stream())
+    if obs is not None:
+        obs.end()
 
 
 class _ConvFn(Function):
@@ -144,7 +157,7 @@ class _ConvFn(Function):
         gf, pf, gd, pd, (OH, OW) = conv_geoms(kind, B, Cin, H, W, Cout, kh)
         out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
-        _gather(x, packed_weight(w, pf, cache), b, gf, out)
+        _gather(x, packed_weight(w, pf, cache), b, gf, out, kind, "fwd")
         ctx.save_for_backward(x, w)
         ctx.kind, ctx.has_bias, ctx.cache = kind, bias is not None, cache
         return out
@@ -160,13 +173,18 @@ class _ConvFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx)
+            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             lib = L.load()
             nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
             ws, wsp = _ws(nbytes, x)
+            obs = _OBSERVER[0]
+            if obs is not None:
+                obs.begin(ctx.kind, "wgrad", gf)
             L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dw), byref(gf), pf, kh, kw, _PRECISION[0], wsp, nbytes, _stream())
+            if obs is not None:
+                obs.end()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=torch.float32, device=x.device)
             L.call("agan_bias_grad", _p(dy), _p(db), B, Cout, dy.shape[2] * dy.shape[3], _stream())

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""AttnGAN stage-3 training throughput on MI355X (BASELINE.json metric: train images/s at 256x256, batch 24/GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full GanTrainer batch (train.py:109-151): G forward (3 stages + 2 word attentions), three discriminator
+updates (real + fake batch each), the generator update through all three discriminators + DAMSM words/sentence loss + KL,
+four fused Adam steps; under N > 1 every rank runs its own 24-image shard (weak scaling) and weight gradients are
+all-reduced over RCCL.  Inputs are synthetic and already resident in HBM when the timed region starts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# hyper-parameters of the metric configuration (train.py:34-49; BASELINE.json configs[2])
+GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def algorithmic_conv_flops(kind, B, Cin, H, W, Cout, k):
+    """2*MAC of the REFERENCE convolution: the upsample conv is priced at 9 taps on the 2x grid even
+    though the folded kernel executes 4/9 of those MACs."""
+    if kind == "same":
+        return 2.0 * B * H * W * Cout * Cin * k * k
+    if kind == "down":
+        return 2.0 * B * (H // 2) * (W // 2) * Cout * Cin * 16
+    if kind == "up":
+        return 2.0 * B * (2 * H) * (2 * W) * Cout * Cin * 9
+    raise ValueError(kind)
+
+
+class ConvTimer:
+    """HIP-event pairs around every conv-engine launch (the events go on torch's current stream, which is the stream the
+    kernels are enqueued on); durations are read after the timed region has been synchronised."""
+
+    def __init__(self):
+        self.records, self.enabled, self._open = [], False, None
+
+    def begin(self, kind, phase, g):
+        if not self.enabled:
+            return
+        K = g.Cin * g.R * g.S
+        executed = 2.0 * g.B * g.OH * g.OW * g.Cout * K          # MACs the kernel really issues (x2)
+        # algorithmic = the REFERENCE's contraction for this call: Upsample+conv3x3 is 9 taps on the 2x grid,
+        # the folded kernels (fwd: 4 classes x 2x2 taps; dgrad: 4x4 s2; wgrad: 4 classes) execute 4/9 of that.
+        algorithmic = executed * (9.0 / 4.0) if kind == "up" else executed
+        tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
+        name = f"conv_wgrad_f32" if phase == "wgrad" else f"conv_gather_f32_{tile}"
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._open = (name, algorithmic, executed, e0)
+
+    def end(self):
+        if self._open is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append(self._open + (e1,))
+        self._open = None
+
+    def summary(self):
+        by = {}
+        for name, fa, fe, e0, e1 in self.records:
+            d = by.setdefault(name, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fa; d[3] += fe
+        return by
+
+
+def build(dev, batch, HF):
+    GEN = importlib.import_module("attention-gan_amd.networks.generator")
+    DISC = importlib.import_module("attention-gan_amd.networks.discriminators")
+    ENC = importlib.import_module("attention-gan_amd.networks.cnn_encoder")
+    TR = importlib.import_module("attention-gan_amd.trainers.trainer")
+    torch.manual_seed(0)      # identical initial weights on every rank (and broadcast from rank 0 on top)
+    G = GEN.Generator(GF, EMB, Z, COND).to(dev)
+    Ds = [DISC.Disc64(DF).to(dev), DISC.Disc128(DF).to(dev), DISC.Disc256(DF).to(dev)]
+    enc = ENC.StandInImageEncoder(EMB).to(dev)
+    enc.freeze_all_weights()
+    return TR.GanTrainStep(G, Ds, enc)
+
+
+def synthetic_batch(dev, batch, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    words = torch.randn(batch, EMB, T, generator=g).to(dev)             # frozen RNN bypassed: N(0,1) embeddings
+    sent = torch.randn(batch, EMB, generator=g).to(dev)
+    lens = [T] * batch
+    reals = [(torch.rand(batch, 3, r, r, generator=g) * 2 - 1).to(dev) for r in (64, 128, 256)]
+    return words, sent, lens, reals
+
+
+def cpu_baseline(batch):
+    """The CPU oracle (a port of the reference's step) timed on this box's host cores: one full step at the metric shapes."""
+    from oracle import attngan_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))        # a one-GPU box shares 16 host cores; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: timing the CPU oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    gp = O.make_generator_params(GF, EMB, Z, COND, seed=0)
+    dps = [O.make_disc_params(DF, r, seed=0) for r in (64, 128, 256)]
+    gopt, dopts = O.AdamState(gp), [O.AdamState(d) for d in dps]
+    ep = O.standin_encoder_params(EMB)
+    g = torch.Generator().manual_seed(0)
+    words, sent = torch.randn(batch, EMB, T, generator=g), torch.randn(batch, EMB, generator=g)
+    reals = [torch.rand(batch, 3, r, r, generator=g) * 2 - 1 for r in (64, 128, 256)]
+    noise, eps = torch.randn(batch, Z, generator=g), torch.randn(batch, COND, generator=g)
+    t0 = time.perf_counter()
+    O.train_step(gp, dps, gopt, dopts, words, sent, [T] * batch, None, reals, noise, eps, lambda im: O.standin_encoder(im, ep))
+    dt = time.perf_counter() - t0
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 full train step, batch {batch}, same shapes as the GPU workload (no warm-up), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    step = build(dev, args.batch, HF)
+    words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
+    timer = ConvTimer()
+    HF.set_launch_observer(timer)
+
+    def one_step():
+        return step.step(words, sent, lens, None, reals)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = all(bool(torch.isfinite(out[k]).all()) for k in ("d_loss2", "g_total"))
+
+    if rank == 0:
+        summ = timer.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1][1]) if summ else None
+        roofline = None
+        if dom:
+            name, (n, ms, falg, fexec) = dom
+            achieved = falg / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": n, "avg_launch_ms": round(ms / n, 4), "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),
+                        "share_of_step_time": round(ms / (elapsed * 1e3), 3)}
+        line = {
+            "metric": "train images/sec at 256x256 stage-3, batch 24/GPU",
+            "value": round(world * args.batch * args.steps / elapsed, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full 3-stage AttnGAN 64->128->256 train step: G + 3xD updates + word attention + DAMSM words/sentence "
+                                   "loss + KL + 4x fused Adam (BASELINE.json configs[2])",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "gf_dim": GF, "df_dim": DF, "emb_dim": EMB,
+                       "seq_len": T, "image_encoder": "frozen stand-in plug-in (pool+projection); Inception-v3 trunk is SURVEY row f1",
+                       "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}", "losses_finite": finite},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
