@@ -36,8 +36,8 @@ def T(a):
 
 def rel_err(got, want):
     """max |got-want| / max(|want|) -- the 'relative fp tolerance' used throughout (scale of the tensor)."""
-    got = torch.as_tensor(got).double().cpu()
-    want = torch.as_tensor(want).double().cpu()
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
     scale = want.abs().max().clamp(min=1e-30)
     return float((got - want).abs().max() / scale)
 

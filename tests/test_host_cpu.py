@@ -1,0 +1,196 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/agan.h declares, the host mirror of
+the reference interface has the reference's state_dict keys / parameter counts / initialisation, the product path refuses
+to run without a GPU (no CPU fallback), and the data-parallel gradient exchange is exercised with gloo, world_size 2."""
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load, sub
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+agan = importlib.import_module("attention-gan_amd")
+L = importlib.import_module("attention-gan_amd.backend.lib")
+GEN = importlib.import_module("attention-gan_amd.networks.generator")
+DISC = importlib.import_module("attention-gan_amd.networks.discriminators")
+LAY = importlib.import_module("attention-gan_amd.utilities.layers")
+OPT = importlib.import_module("attention-gan_amd.optim")
+DP = importlib.import_module("attention-gan_amd.dataparallel")
+TR = importlib.import_module("attention-gan_amd.trainers.trainer")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "agan.h")).read()
+    declared = set(re.findall(r"\b(agan_[a-z0-9_]+)\s*\(", header)) - {"agan_round_up"}
+    lib = L.load()                       # dlopen + prototype attach raises if anything is missing
+    assert lib.agan_version() == 100
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(agan_[a-z0-9_]+)\b", out))
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert declared == set(L.EXPORTED_SYMBOLS), sorted(declared ^ set(L.EXPORTED_SYMBOLS))
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Entry points validate arguments before touching the device: bad geometry comes back as AGAN_EINVAL + message."""
+    lib = L.load()
+    g = L.ConvGeom()
+    assert lib.agan_conv_gather_ws_bytes(g) == 0
+    assert lib.agan_packed_weight_elems(L.PACK_UP_FWD, 8, 8, 4, 4) == 0          # folded upsample conv is 3x3 only
+    assert lib.agan_packed_weight_elems(L.PACK_FWD, 3, 32, 3, 3) == 32 * 9 * 32   # Nld = round_up(3, 32)
+    assert lib.agan_packed_weight_elems(L.PACK_UP_FWD, 64, 64, 3, 3) == 4 * 64 * 4 * 64
+    rc = lib.agan_conv_gather(None, None, None, None, g, 0, None, 0, None)
+    assert rc == -1 and b"conv" in lib.agan_last_error()
+
+
+def test_state_dict_keys_and_param_counts_match_reference():
+    g = load("a5_generator")
+    gf, emb, z, cond, _, _ = (int(v) for v in g["dims"])
+    G = GEN.Generator(gf, emb, z, cond)
+    assert set(G.state_dict()) == set(sub(g, "param/"))
+    for k, v in sub(g, "param/").items():
+        assert tuple(G.state_dict()[k].shape) == tuple(v.shape), k
+    for res, cls in ((64, DISC.Disc64), (128, DISC.Disc128), (256, DISC.Disc256)):
+        gd = load(f"a7_disc{res}")
+        D = cls(int(gd["df"]))
+        assert set(D.state_dict()) == set(sub(gd, "param/"))
+    # parameter counts at the metric configuration (probed on the reference)
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(GEN.Generator(32, 256, 100, 100)) == 7_084_592
+    assert [count(c(64)) for c in (DISC.Disc64, DISC.Disc128, DISC.Disc256)] == [2_765_569, 15_875_841, 68_310_785]
+    assert len(GEN.Generator(32, 256, 100, 100).state_dict()) == 97 and len(DISC.Disc256(64).state_dict()) == 45
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/networks"), reason="reference tree not present on this box")
+def test_same_seed_gives_reference_initial_weights():
+    """Module creation order and initialisers follow the reference, so torch.manual_seed(s) reproduces its init bit for bit."""
+    code = (
+        "import sys, torch; sys.path.insert(0, '/root/reference'); sys.dont_write_bytecode = True\n"
+        "from networks.generator import Generator; from networks.discriminators import Disc128\n"
+        "torch.manual_seed(7); G = Generator(4, 16, 10, 10); D = Disc128(4)\n"
+        "torch.save({'G': G.state_dict(), 'D': D.state_dict()}, sys.argv[1])\n")
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "agan_ref_init.pt")
+    subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    ref = torch.load(path, weights_only=True)
+    torch.manual_seed(7)
+    G, D = GEN.Generator(4, 16, 10, 10), DISC.Disc128(4)
+    for name, mine in (("G", G), ("D", D)):
+        for k, v in ref[name].items():
+            assert torch.equal(mine.state_dict()[k], v), f"{name}.{k}"
+
+
+def test_no_cpu_fallback():
+    G = GEN.Generator(4, 16, 10, 10)
+    with pytest.raises(L.AganError, match="no CPU fallback"):
+        G(torch.randn(2, 10), torch.randn(2, 16), torch.randn(2, 16, 5), torch.ones(2, 5, dtype=torch.int64), torch.randn(2, 10))
+    with pytest.raises(L.AganError):
+        DISC.Disc64(4)(torch.randn(2, 3, 64, 64))
+
+
+def test_layers_factory_surface():
+    assert LAY.Layers.calculate_out_hw(64, 4, 2, 1) == 32
+    with pytest.raises(AssertionError, match="channels dont divide 2"):
+        LAY.Layers.GLU()(torch.randn(1, 3, 2, 2))
+    c = LAY.Layers.conv(8, 8, 16, 8)
+    assert (c.kernel_size, c.stride, c.padding) == ((4, 4), (2, 2), (1, 1))
+    assert set(LAY.Layers.upBlock(8, 4).state_dict()) == {"1.weight", "2.weight", "2.bias", "2.running_mean", "2.running_var", "2.num_batches_tracked"}
+    with pytest.raises(Exception):
+        LAY.Layers.conv(8, 8, 16, 1000)
+
+
+def test_trainer_helpers():
+    t = TR.ModelTrainer()
+    m = t._make_mask(torch.tensor([3, 1, 2]))
+    assert m.tolist() == [[1, 1, 1], [1, 0, 0], [1, 1, 0]] and m.dtype == torch.int64
+    assert t._make_match_labels(4).tolist() == [0, 1, 2, 3]
+    assert tuple(t._make_noise(3, 5).shape) == (3, 5)
+    assert torch.allclose(t._denormalise_single(torch.tensor([-1.0, 1.0])), torch.tensor([0.0, 1.0]))
+
+
+def test_flat_adam_rehomes_parameters_and_speaks_adam_state_dict():
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    before = {k: v.clone() for k, v in lin.state_dict().items()}
+    opt = OPT.FlatAdam(lin.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    for k, v in lin.state_dict().items():
+        assert torch.equal(v, before[k])
+    base = opt.flat.data_ptr()
+    for p, o in zip(opt.params, opt.offsets):
+        assert p.data_ptr() == base + 4 * o and o % 4 == 0 and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * o
+    lin(torch.randn(2, 5)).sum().backward()
+    assert float(opt.grad.abs().sum()) > 0                      # autograd accumulated straight into the flat buffer
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)).parameters(), lr=2e-4, betas=(0.5, 0.999))
+    assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "params"} and sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+
+
+def test_grad_bucket_partition():
+    mods = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(6)])
+    opt = OPT.FlatAdam(mods.parameters())
+    bk = DP.GradBuckets(opt, bucket_bytes=2 * 64 * 64 * 4)
+    assert bk.bounds[0][0] == 0 and bk.bounds[-1][1] == opt.numel
+    assert all(a[1] == b[0] for a, b in zip(bk.bounds, bk.bounds[1:]))         # contiguous cover
+    assert len(bk.bounds) >= 3 and sum(bk.counts) == len(opt.params)
+    assert bk.finish() == 1.0
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                                         # different init per rank on purpose
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
+        DP.broadcast_module_(net, 0)
+        opt = OPT.FlatAdam(net.parameters())
+        bk = DP.GradBuckets(opt, bucket_bytes=16 * 32 * 4)                    # several buckets
+        x = torch.randn(4, 16, generator=torch.Generator().manual_seed(rank))
+        opt.zero_grad()
+        bk.arm()
+        net(x).pow(2).sum().backward()
+        local = None
+        scale = bk.finish()
+        q.put((rank, scale, opt.flat.clone(), opt.grad.clone(), len(bk.bounds)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, w0, g0, nb0), (r1, s1, w1, g1, nb1) = got
+    assert s0 == s1 == 0.5 and nb0 == nb1 and nb0 > 1
+    assert torch.equal(w0, w1)                                   # broadcast made the replicas identical
+    assert torch.equal(g0, g1)                                   # both hold the SUM of the two shards' gradients
+    # single-process check: sum of per-shard gradients on the same weights
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
+    opt = OPT.FlatAdam(net.parameters())
+    with torch.no_grad():
+        opt.flat.copy_(w0)
+    total = torch.zeros_like(opt.grad)
+    for r in range(2):
+        opt.zero_grad()
+        net(torch.randn(4, 16, generator=torch.Generator().manual_seed(r))).pow(2).sum().backward()
+        total += opt.grad
+    assert torch.allclose(g0, total, rtol=1e-5, atol=1e-6)
+
+
+def test_golden_fixtures_are_data_only():
+    for f in os.listdir(GOLDEN):
+        if f.endswith(".npz"):
+            z = np.load(os.path.join(GOLDEN, f), allow_pickle=False)
+            assert all(z[k].dtype.kind in "fiub" for k in z.files), f
