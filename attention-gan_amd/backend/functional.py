@@ -125,6 +125,21 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     return wk
 
 
+_KTABLE_CACHE = {}
+
+
+def ktable(g: L.ConvGeom, device) -> Tensor:
+    """Reduction-index table of a geometry (include/agan.h: agan_conv_ktable), built once per (geometry, device)."""
+    key = (g.Cin, g.IH, g.IW, g.R, g.S, g.DY, str(device))
+    t = _KTABLE_CACHE.get(key)
+    if t is None:
+        n = L.load().agan_conv_ktable_elems(byref(g))
+        t = torch.empty(n, dtype=torch.int32, device=device)
+        L.call("agan_conv_ktable", byref(g), _p(t), _stream())
+        _KTABLE_CACHE[key] = t
+    return t
+
+
 # optional launch observer (bench.py times the conv engine with HIP events through it): begin(kind, phase, geom) / end()
 _OBSERVER = [None]
 
@@ -137,10 +152,11 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
     lib = L.load()
     nbytes = lib.agan_conv_gather_ws_bytes(byref(g))
     ws, wsp = _ws(nbytes, x)
+    kt = ktable(g, x.device)
     obs = _OBSERVER[0]
     if obs is not None:
         obs.begin(kind, phase, g)
-    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _PRECISION[0], wsp, nbytes, _stream())
+    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], wsp, nbytes, _stream())
     if obs is not None:
         obs.end()
 
@@ -179,10 +195,11 @@ class _ConvFn(Function):
             lib = L.load()
             nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
             ws, wsp = _ws(nbytes, x)
+            kt = ktable(gf, x.device)
             obs = _OBSERVER[0]
             if obs is not None:
                 obs.begin(ctx.kind, "wgrad", gf)
-            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dw), byref(gf), pf, kh, kw, _PRECISION[0], wsp, nbytes, _stream())
+            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dw), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wsp, nbytes, _stream())
             if obs is not None:
                 obs.end()
         if ctx.has_bias and ctx.needs_input_grad[2]:

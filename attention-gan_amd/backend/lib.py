@@ -33,9 +33,11 @@ _SIGNATURES = {
     "agan_packed_weight_elems": (c_size_t, [c_int] * 5),
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
-    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), c_int, _P, c_size_t, _P]),
+    "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
+    "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
+    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, _P, c_size_t, _P]),
     "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
-    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),

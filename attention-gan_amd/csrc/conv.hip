@@ -20,10 +20,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// n / d for n < 2^31 by multiply-high (Granlund-Montgomery round-up form): 2 VALU ops instead of a ~40-instruction sequence
+struct FastDiv {
+    unsigned mul, shift;
+    __device__ __forceinline__ int div(int n) const { return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> shift); }
+};
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.shift = l;
+    return f;
+}
+
 struct Geom {
     int B, Cin, IH, IW, Cout, OH, OW, R, S, OS, SY, DY, OY0, OY1;
     int OHs, OWs, HWs, Mtot, K, Nld, RS;
+    FastDiv dHWs, dOWs;
 };
+
+// Reduction-index table: entry k = (ci, r, s) -> { element offset ci*IH*IW + r*DY*IW + s*DY , packed (dy = r*DY, dx = s*DY) }.
+// Built once per geometry (agan_conv_ktable) and read with scalar loads, so the kernels spend no ALU work on decoding k.
+// Entries >= K are sentinels whose dy fails every range check.
+constexpr int kTabPad = 128;
+constexpr int kSentinelDy = -32768;
+__host__ __device__ inline int ktable_entries(int K) { return (K + kTabPad - 1) / kTabPad * kTabPad + kTabPad; }
 
 Geom make_geom(const agan_conv_geom* g) {
     Geom d;
@@ -31,6 +53,7 @@ Geom make_geom(const agan_conv_geom* g) {
     d.R = g->R; d.S = g->S; d.OS = g->OS; d.SY = g->SY; d.DY = g->DY; d.OY0 = g->OY[0]; d.OY1 = g->OY[1];
     d.OHs = g->OH / g->OS; d.OWs = g->OW / g->OS; d.HWs = d.OHs * d.OWs; d.Mtot = g->B * d.HWs;
     d.RS = g->R * g->S; d.K = g->Cin * d.RS; d.Nld = agan_round_up(g->Cout, 32);
+    d.dHWs = make_fastdiv((unsigned)d.HWs); d.dOWs = make_fastdiv((unsigned)d.OWs);
     return d;
 }
 
@@ -42,26 +65,43 @@ int check_geom(const agan_conv_geom* g) {
     AGAN_REQUIRE(g->OS == 1 || g->OS == 2, "conv: OS must be 1 or 2");
     AGAN_REQUIRE(g->OH % g->OS == 0 && g->OW % g->OS == 0, "conv: OH/OW not divisible by OS");
     const long long in_elems = 1LL * g->B * g->Cin * g->IH * g->IW, out_elems = 1LL * g->B * g->Cout * g->OH * g->OW;
-    AGAN_REQUIRE(in_elems < (1LL << 31) && out_elems < (1LL << 31), "conv: tensor exceeds 2^31 elements");
+    AGAN_REQUIRE(in_elems < (1LL << 30) && out_elems < (1LL << 30), "conv: tensor exceeds 2^30 elements (32-bit buffer offsets)");
     return AGAN_OK;
 }
 
-// (c, r, s) counter advanced on the scalar unit
-struct KIdx {
-    int c, r, s;
-    __device__ __forceinline__ void set(int k, int RS, int S) {
-        c = k / RS;
-        const int rs = k - c * RS;
-        r = rs / S;
-        s = rs - r * S;
+__global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int n, int K, int RS, int S, int IHW, int IW, int DY) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    int2 e;
+    if (k < K) {
+        const int c = k / RS, rs = k - c * RS, r = rs / S, q = rs - r * S;
+        const int dy = r * DY, dx = q * DY;
+        e.x = c * IHW + dy * IW + dx;
+        e.y = (dy & 0xFFFF) | (dx << 16);
+    } else {
+        e.x = 0;
+        e.y = kSentinelDy & 0xFFFF;
     }
-    __device__ __forceinline__ void step(int R, int S) {
-        if (++s == S) {
-            s = 0;
-            if (++r == R) { r = 0; ++c; }
-        }
-    }
-};
+    tab[k] = e;
+}
+
+// Raw buffer resources: the hardware range check turns every out-of-image / out-of-tile access into a zero load
+// (or a dropped store) -- no exec-mask branches around the gathers (cdna_hip_programming.md T8).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
 
 // ================================================================================================
 // forward / dgrad gather kernel
@@ -69,8 +109,8 @@ struct KIdx {
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               const Geom g, const int ksplit, const int kchunk,
-                                                               const size_t slab) {
+                                                               const int2* __restrict__ ktab, const Geom g, const int ksplit,
+                                                               const int kchunk, const size_t slab) {
     constexpr int BK = 16;
     constexpr int NG = 256 / BM;       // wave-uniform k groups for the pixel-major A loads
     constexpr int AK = BK / NG;        // k rows per thread per tile
@@ -91,58 +131,61 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = split * kchunk, kend = min(g.K, kbeg + kchunk);
     const int nkt = cdiv(kend - kbeg, BK);
+    const int ihw = g.IH * g.IW;
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(wk + (size_t)cls * g.K * g.Nld, (size_t)g.K * g.Nld * sizeof(float));
 
     // ---- per-thread pixel for the A gather -------------------------------------------------------
     const int am = tid % BM;
     const int akg = __builtin_amdgcn_readfirstlane(tid / BM);
     const int m = m0 + am;
     const bool mvalid = m < g.Mtot;
-    int iy0, ix0;
-    const float* inb;
+    int iy0, ix0, pix0;   // pix0: element offset of (b, c=0, iy0, ix0) -- may point outside the image, used only when valid
     {
         const int mm = mvalid ? m : 0;
-        const int b = mm / g.HWs, rem = mm - b * g.HWs;
-        const int yq = rem / g.OWs, xq = rem - yq * g.OWs;
+        const int b = g.dHWs.div(mm), rem = mm - b * g.HWs;
+        const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
         iy0 = yq * g.SY + (py ? g.OY1 : g.OY0);
         ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
-        inb = in + (size_t)b * g.Cin * g.IH * g.IW;
+        pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
+        if (!mvalid) iy0 = -(1 << 20);      // every tap of a padding row fails the range check
     }
-    const float* wkc = wk + (size_t)cls * g.K * g.Nld;
+    // B tile mapping
+    int bkr[BV], bnc[BV];
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+        const int f = tid + j * 256;
+        bkr[j] = f / (BN / 4);
+        bnc[j] = (f - bkr[j] * (BN / 4)) * 4;
+    }
 
     float areg[AK];
-    float4 breg[BV];
+    f32x4 breg[BV];
 
     auto load_tile = [&](int kt) {
         const int kb = kbeg + kt * BK;
-        int k = kb + akg * AK;
-        KIdx ki;
-        ki.set(k, g.RS, g.S);
+        const int2* tk = ktab + kb + akg * AK;          // wave-uniform -> scalar loads
 #pragma unroll
         for (int i = 0; i < AK; ++i) {
-            const int iy = iy0 + ki.r * g.DY, ix = ix0 + ki.s * g.DY;
-            const bool ok = mvalid && (k + i) < kend && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-            areg[i] = ok ? inb[(ki.c * g.IH + iy) * g.IW + ix] : 0.f;
-            ki.step(g.R, g.S);
+            const int2 e = tk[i];
+            const int dy = (int)(short)(e.y & 0xFFFF), dx = e.y >> 16;
+            const bool ok = ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
+            areg[i] = buf_load(rin, ok ? (unsigned)(pix0 + e.x) * 4u : kOOB);
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
-            const int f = tid + j * 256;
-            const int kr = f / (BN / 4), nc = (f - kr * (BN / 4)) * 4;
-            const int kk = kb + kr, n = n0 + nc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < NB4 && kk < kend && n < g.Nld) v = *reinterpret_cast<const float4*>(wkc + (size_t)kk * g.Nld + n);
-            breg[j] = v;
+            const int kk = kb + bkr[j], n = n0 + bnc[j];
+            const bool ok = (BV * 256 == NB4 || tid + j * 256 < NB4) & (kk < kend) & (n < g.Nld);
+            breg[j] = buf_load4(rwk, ok ? (unsigned)(kk * g.Nld + n) * 4u : kOOB);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AK; ++i) As[buf][akg * AK + i][am] = areg[i];
 #pragma unroll
-        for (int j = 0; j < BV; ++j) {
-            const int f = tid + j * 256;
-            const int kr = f / (BN / 4), nc = (f - kr * (BN / 4)) * 4;
-            if (f < NB4) *reinterpret_cast<float4*>(&Bs[buf][kr][nc]) = breg[j];
-        }
+        for (int j = 0; j < BV; ++j)
+            if (BV * 256 == NB4 || tid + j * 256 < NB4) *reinterpret_cast<f32x4*>(&Bs[buf][bkr[j]][bnc[j]]) = breg[j];
     };
 
     f32x16 acc[TN][TM];
@@ -182,26 +225,26 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
     }
 
     // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ---
-    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
-    const bool add_bias = (bias != nullptr) && (ksplit == 1);
     const size_t ohw = (size_t)g.OH * g.OW;
+    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const bool add_bias = (bias != nullptr) && (ksplit == 1);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mo = m0 + wm * WTM + tm * 32 + l31;
-        if (mo >= g.Mtot) continue;
-        const int b = mo / g.HWs, rem = mo - b * g.HWs;
-        const int yq = rem / g.OWs, xq = rem - yq * g.OWs;
-        const size_t pixoff = (size_t)b * g.Cout * ohw + (size_t)(yq * g.OS + py) * g.OW + (xq * g.OS + px);
+        const bool pvalid = mo < g.Mtot;
+        const int mm = pvalid ? mo : 0;
+        const int b = g.dHWs.div(mm), rem = mm - b * g.HWs;
+        const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
+        const unsigned pixoff = (unsigned)(b * g.Cout) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * WTN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n < g.Cout) {
-                    float v = acc[tn][tm][r];
-                    if (add_bias) v += bias[n];
-                    dst[pixoff + (size_t)n * ohw] = v;
-                }
+                float v = acc[tn][tm][r];
+                if (add_bias) v += bias[min(n, g.Cout - 1)];
+                buf_store(rout, (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB, v);
             }
         }
     }
@@ -261,10 +304,10 @@ GatherPlan plan_gather(const Geom& g) {
 }
 
 template <int BN, int WM, int WN>
-void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const Geom& g, const GatherPlan& p,
-                   hipStream_t st) {
+void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
+                   const GatherPlan& p, hipStream_t st) {
     dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
-    hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN>), grid, dim3(256), 0, st, in, wk, bias, dst, g, p.ksplit,
+    hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
                        p.kchunk, p.slab);
 }
 
@@ -273,8 +316,8 @@ void launch_gather(const float* in, const float* wk, const float* bias, float* d
 // ================================================================================================
 template <int BI, int BJ>
 __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ dst, const Geom g, const int psplit,
-                                                              const int pchunk, const size_t slab) {
+                                                              float* __restrict__ dst, const int2* __restrict__ ktab, const Geom g,
+                                                              const int psplit, const int pchunk, const size_t slab) {
     constexpr int BP = 32, LDP = 33;   // +1 pad: MFMA operand reads walk the row index across lanes
     constexpr int XR = BI / 8, YR = BJ / 8;   // rows per thread per tile
     constexpr int TI = BI / 64, TJ = BJ / 64;
@@ -290,7 +333,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     const int pbeg = split * pchunk, pend = min(g.Mtot, pbeg + pchunk);
     const int npt = cdiv(pend - pbeg, BP);
     const int pl = lane & 31, half = lane >> 5;
-    const size_t ohw = (size_t)g.OH * g.OW;
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int2* tk = ktab + i0 + wave * (BI / 4);          // this wave's 32 (BI=128) / 16 (BI=64) reduction rows: scalar loads
+    const int nb = j0 + wave * (BJ / 4) + half;
 
     float xreg[XR], yreg[YR];
 
@@ -298,32 +345,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         const int p = pbeg + pt * BP + pl;
         const bool pvalid = p < pend;
         const int pp = pvalid ? p : 0;
-        const int b = pp / g.HWs, rem = pp - b * g.HWs;
-        const int yq = rem / g.OWs, xq = rem - yq * g.OWs;
-        const int iy0 = yq * g.SY + (py ? g.OY1 : g.OY0), ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
-        const float* xb = x + (size_t)b * g.Cin * g.IH * g.IW;
-        const float* dyb = dy + (size_t)b * g.Cout * ohw + (size_t)(yq * g.OS + py) * g.OW + (xq * g.OS + px);
-        // rows owned by this wave: wave*(BI/4) + 2*ii + half   (two consecutive k indices per wave access)
-        int ka = i0 + wave * (BI / 4);
-        KIdx ia;
-        ia.set(ka, g.RS, g.S);
+        const int b = g.dHWs.div(pp), rem = pp - b * g.HWs;
+        const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
+        const int iy0 = pvalid ? yq * g.SY + (py ? g.OY1 : g.OY0) : -(1 << 20);
+        const int ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
+        const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
+        const int dyoff = b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px);
 #pragma unroll
         for (int ii = 0; ii < XR; ++ii) {
-            KIdx ib = ia;
-            ib.step(g.R, g.S);
-            const int c = half ? ib.c : ia.c, r = half ? ib.r : ia.r, s = half ? ib.s : ia.s;
-            const int iy = iy0 + r * g.DY, ix = ix0 + s * g.DY;
-            const bool ok = pvalid && (ka + half) < g.K && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-            xreg[ii] = ok ? xb[(c * g.IH + iy) * g.IW + ix] : 0.f;
-            ia = ib;
-            ia.step(g.R, g.S);
-            ka += 2;
+            const int2 ea = tk[2 * ii], eb = tk[2 * ii + 1];
+            const int ex = half ? eb.x : ea.x, ey = half ? eb.y : ea.y;
+            const int ddy = (int)(short)(ey & 0xFFFF), ddx = ey >> 16;
+            const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
+            xreg[ii] = buf_load(rx, ok ? (unsigned)(pix0 + ex) * 4u : kOOB);
         }
-        const int nb = j0 + wave * (BJ / 4) + half;
 #pragma unroll
         for (int jj = 0; jj < YR; ++jj) {
             const int n = nb + 2 * jj;
-            yreg[jj] = (pvalid && n < g.Cout) ? dyb[(size_t)n * ohw] : 0.f;
+            yreg[jj] = buf_load(rdy, (pvalid & (n < g.Cout)) ? (unsigned)(dyoff + n * ohw) * 4u : kOOB);
         }
     };
     auto store_tile = [&](int buf) {
@@ -333,11 +372,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         for (int jj = 0; jj < YR; ++jj) Ys[buf][wave * (BJ / 4) + 2 * jj + half][pl] = yreg[jj];
     };
 
-    f32x16 acc[TI][TJ];
+    f32x16 acc[TJ][TI];
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
+    for (int a = 0; a < TJ; ++a)
 #pragma unroll
-        for (int b = 0; b < TJ; ++b)
+        for (int b = 0; b < TI; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -358,27 +397,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 #pragma unroll
             for (int t = 0; t < TJ; ++t) bv[t] = Ys[buf][wj * (BJ / 2) + t * 32 + pl][pp + half];
 #pragma unroll
-            for (int a = 0; a < TI; ++a)
+            for (int a = 0; a < TJ; ++a)
 #pragma unroll
-                for (int b = 0; b < TJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[a], av[b], acc[a][b], 0, 0, 0);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    // D[i = k index][j = cout]: lane owns cout column, registers walk k rows
-    float* o = dst + (size_t)split * slab + (size_t)cls * g.K * g.Nld;
+    // D[cout][k index]: the lane owns one k column, so each register stores 32 consecutive floats of an OIHW row
+    float* o = dst + (size_t)split * slab + (size_t)cls * g.Cout * g.K;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)g.Cout * g.K * sizeof(float));
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+    for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) {
-            const int n = j0 + wj * (BJ / 2) + tj * 32 + pl;
+        for (int ti = 0; ti < TI; ++ti) {
+            const int i = i0 + wi * (BI / 2) + ti * 32 + pl;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wi * (BI / 2) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (i < g.K && n < g.Nld) o[(size_t)i * g.Nld + n] = acc[ti][tj][r];
+                const int n = j0 + wj * (BJ / 2) + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                buf_store(ro, ((i < g.K) & (n < g.Cout)) ? (unsigned)(n * g.K + i) * 4u : kOOB, acc[tj][ti][r]);
             }
         }
 }
@@ -388,7 +428,7 @@ struct WgradPlan {
     size_t slab, ws_bytes;
 };
 
-WgradPlan plan_wgrad(const Geom& g) {
+WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     WgradPlan p;
     p.bi = g.K >= 96 ? 128 : 64;
     p.bj = g.Cout >= 96 ? 128 : 64;
@@ -398,11 +438,13 @@ WgradPlan plan_wgrad(const Geom& g) {
     const int tiles = p.itiles * p.jtiles * p.ncls;
     const int ptiles = cdiv(g.Mtot, 32);
     int ps = 1;
-    if (tiles < 512) ps = std::min({cdiv(1024, tiles), std::max(1, ptiles / 8), 512});
+    if (tiles < 1024) ps = std::min({cdiv(1024, tiles), std::max(1, ptiles / 4), 2048});
     p.pchunk = cdiv(ptiles, ps) * 32;
     p.psplit = cdiv(g.Mtot, p.pchunk);
-    p.slab = (size_t)p.ncls * g.K * g.Nld;
-    p.ws_bytes = p.slab * p.psplit * sizeof(float);
+    p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
+    // partial slabs (only when split) + one reduced slab when a tap-combine pass follows
+    const size_t nslabs = (p.psplit > 1 ? p.psplit : 0) + (needs_combine ? 1 : 0);
+    p.ws_bytes = p.slab * nslabs * sizeof(float);
     return p;
 }
 
@@ -467,31 +509,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
-// FWD mode: dw[co][k] = sum_split dwk[split][k][co]  -- tiled transpose, coalesced both ways
-__global__ __launch_bounds__(256) void unpack_wgrad_fwd_kernel(const float* __restrict__ dwk, int nsplit, size_t slab,
-                                                               float* __restrict__ dw, int cout, int K, int Nld) {
-    __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + ty + j * 8, n = n0 + tx;
-        float v = 0.f;
-        if (k < K && n < Nld)
-            for (int s = 0; s < nsplit; ++s) v += dwk[(size_t)s * slab + (size_t)k * Nld + n];
-        tile[ty + j * 8][tx] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + ty + j * 8, k = k0 + tx;
-        if (n < cout && k < K) dw[(size_t)n * K + k] = tile[tx][ty + j * 8];
-    }
-}
-
-// UP mode: dw[co][ci][a][b] = sum over the (class, tap) pairs that 3x3 tap (a,b) was folded into
-__global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __restrict__ dwk, int nsplit, size_t slab,
-                                                              float* __restrict__ dw, int cout, int cin, int Nld) {
+// UP mode: dw[co][ci][a][b] = sum over the (class, tap) pairs that 3x3 tap (a,b) was folded into; dwk is [cls][co][(ci,r,s)]
+__global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int cout, int cin) {
     const int K = cin * 4;
     const size_t total = (size_t)cout * cin * 9;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -505,12 +524,11 @@ __global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __res
                 up_fwd_taps(py, r, rl, rh);
                 if (a < rl || a > rh) continue;
                 for (int px = 0; px < 2; ++px)
-                    for (int s = 0; s < 2; ++s) {
+                    for (int q = 0; q < 2; ++q) {
                         int sl, sh;
-                        up_fwd_taps(px, s, sl, sh);
+                        up_fwd_taps(px, q, sl, sh);
                         if (b < sl || b > sh) continue;
-                        const size_t off = ((size_t)(py * 2 + px) * K + (ci * 4 + r * 2 + s)) * Nld + co;
-                        for (int sp = 0; sp < nsplit; ++sp) v += dwk[(size_t)sp * slab + off];
+                        v += dwk[((size_t)(py * 2 + px) * cout + co) * K + (ci * 4 + r * 2 + q)];
                     }
             }
         dw[e] = v;
@@ -571,10 +589,26 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g) {
     return plan_gather(make_geom(g)).ws_bytes;
 }
 
-int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* gg, int prec,
-                     void* ws, size_t ws_bytes, void* stream) {
+size_t agan_conv_ktable_elems(const agan_conv_geom* g) {
+    if (check_geom(g)) return 0;
+    return (size_t)ktable_entries(g->Cin * g->R * g->S) * 2;
+}
+
+int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
     if (int e = check_geom(gg)) return e;
-    AGAN_REQUIRE(in && wk && out, "conv_gather: null pointer");
+    AGAN_REQUIRE(table != nullptr, "conv_ktable: null pointer");
+    const Geom g = make_geom(gg);
+    const int n = ktable_entries(g.K);
+    hipLaunchKernelGGL(ktable_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<int2*>(table), n, g.K, g.RS,
+                       g.S, g.IH * g.IW, g.IW, g.DY);
+    return check_launch("conv_ktable");
+}
+
+int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
+                     int prec, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_geom(gg)) return e;
+    AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
+    const int2* ktab = reinterpret_cast<const int2*>(ktable);
     AGAN_REQUIRE(prec == AGAN_PREC_F32, "conv_gather: precision mode %d not built in this version", prec);
     const Geom g = make_geom(gg);
     const GatherPlan p = plan_gather(g);
@@ -584,9 +618,9 @@ int agan_conv_gather(const float* in, const float* wk, const float* bias, float*
     }
     hipStream_t st = as_stream(stream);
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
-    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, g, p, st);
-    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, g, p, st);
-    else launch_gather<32, 4, 1>(in, wk, bias, dst, g, p, st);
+    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
+    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
+    else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, st);
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
@@ -600,42 +634,51 @@ int agan_conv_gather(const float* in, const float* wk, const float* bias, float*
 
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (check_geom(g)) return 0;
-    return plan_wgrad(make_geom(g)).ws_bytes;
+    return plan_wgrad(make_geom(g), g->OS == 2).ws_bytes;
 }
 
-int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, int pack_mode, int kh, int kw,
-                    int prec, void* ws, size_t ws_bytes, void* stream) {
+int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
+                    int kh, int kw, int prec, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_geom(gg)) return e;
-    AGAN_REQUIRE(x && dy && dw && ws, "conv_wgrad: null pointer");
+    AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32, "conv_wgrad: precision mode %d not built in this version", prec);
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
-    if (pack_mode == AGAN_PACK_FWD) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
+    const bool up = pack_mode == AGAN_PACK_UP_FWD;
+    if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
-    const WgradPlan p = plan_wgrad(g);
-    if (p.ws_bytes > ws_bytes) {
+    const WgradPlan p = plan_wgrad(g, up);
+    if (p.ws_bytes > ws_bytes || (p.ws_bytes && !ws)) {
         set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, p.ws_bytes);
         return AGAN_EWORKSPACE;
     }
     hipStream_t st = as_stream(stream);
-    float* part = static_cast<float*>(ws);
+    const int2* ktab = reinterpret_cast<const int2*>(ktable);
+    float* wsf = static_cast<float*>(ws);
+    // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine
+    float* reduced = up ? wsf + (p.psplit > 1 ? p.slab * p.psplit : 0) : dw;
+    float* part = p.psplit > 1 ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
-#define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, g, p.psplit, p.pchunk, p.slab)
+#define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab)
     if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
     else if (p.bi == 128) AGAN_WG(128, 64);
     else if (p.bj == 128) AGAN_WG(64, 128);
     else AGAN_WG(64, 64);
 #undef AGAN_WG
     if (int e = check_launch("conv_wgrad")) return e;
-    if (pack_mode == AGAN_PACK_FWD) {
-        dim3 ug(cdiv(g.K, 32), cdiv(g.Cout, 32));
-        hipLaunchKernelGGL(unpack_wgrad_fwd_kernel, ug, dim3(256), 0, st, part, p.psplit, p.slab, dw, g.Cout, g.K, g.Nld);
-    } else {
+    const size_t n = (size_t)p.ncls * g.Cout * g.K;
+    if (p.psplit > 1) {
+        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 256), 4096);
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, p.psplit, n, p.slab, (const float*)nullptr, 1, 1, reduced);
+        if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
+    }
+    if (up) {
         const size_t total = (size_t)g.Cout * g.Cin * 9;
         hipLaunchKernelGGL(unpack_wgrad_up_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st,
-                           part, p.psplit, p.slab, dw, g.Cout, g.Cin, g.Nld);
+                           reduced, dw, g.Cout, g.Cin);
+        return check_launch("conv_wgrad/unpack");
     }
-    return check_launch("conv_wgrad/unpack");
+    return AGAN_OK;
 }
 
 int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, void* stream) {

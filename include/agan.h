@@ -84,16 +84,22 @@ int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int
 /* conv forward / dgrad: replaces F.conv2d fwd+dgrad under Layers.conv3x3 / conv4x4 s2 / Upsample+conv3x3 /
  * nn.Linear (1x1 on a 1x1 image) -- utilities/layers.py:50-53,64-65,122,139-150; generator_submodules.py:36,152;
  * discriminators.py:15.   bias may be NULL. */
+/* Reduction-index table of a geometry (one int32 pair per k = (ci,r,s), padded): build it once per geometry with
+ * agan_conv_ktable() into agan_conv_ktable_elems() int32s and pass it to every conv call of that geometry.  It lets the
+ * kernels fetch the im2col offsets with scalar loads instead of decoding k with integer divisions. */
+size_t agan_conv_ktable_elems(const agan_conv_geom* g);
+int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
+
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g);
 int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* g,
-                     int prec, void* ws, size_t ws_bytes, void* stream);
+                     const int32_t* ktable, int prec, void* ws, size_t ws_bytes, void* stream);
 
 /* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.
  * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).
  * Replaces the wgrad half of conv2d backward at the same call sites. */
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
-int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, int pack_mode, int kh, int kw,
-                    int prec, void* ws, size_t ws_bytes, void* stream);
+int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
+                    int kh, int kw, int prec, void* ws, size_t ws_bytes, void* stream);
 
 /* dbias[n] = sum_{b,y,x} dy[b,n,y,x]  (bias of nn.Linear / outlogits conv: generator_submodules.py:152, discriminators.py:15) */
 int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, void* stream);
