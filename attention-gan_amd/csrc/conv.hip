@@ -13,6 +13,7 @@
 #include "agan_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 using namespace agan;
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off
 // forward / dgrad gather kernel
 // ================================================================================================
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+__global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                const int2* __restrict__ ktab, const Geom g, const int ksplit,
                                                                const int kchunk, const size_t slab) {
@@ -160,10 +161,13 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
         bnc[j] = (f - bkr[j] * (BN / 4)) * 4;
     }
 
-    float areg[AK];
-    f32x4 breg[BV];
+    // Register staging is two tiles deep: while tile kt is multiplied out of LDS, tile kt+1 is on its way from registers to
+    // the other LDS buffer and the gathers of tile kt+2 are in flight, so the LDS store never waits on HBM/L2 latency.
+    float areg[2][AK];
+    f32x4 breg[2][BV];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](auto set, int kt) {
+        constexpr int P = decltype(set)::value;
         const int kb = kbeg + kt * BK;
         const int2* tk = ktab + kb + akg * AK;          // wave-uniform -> scalar loads
 #pragma unroll
@@ -171,21 +175,22 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
             const int2 e = tk[i];
             const int dy = (int)(short)(e.y & 0xFFFF), dx = e.y >> 16;
             const bool ok = ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
-            areg[i] = buf_load(rin, ok ? (unsigned)(pix0 + e.x) * 4u : kOOB);
+            areg[P][i] = buf_load(rin, ok ? (unsigned)(pix0 + e.x) * 4u : kOOB);
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
             const int kk = kb + bkr[j], n = n0 + bnc[j];
             const bool ok = (BV * 256 == NB4 || tid + j * 256 < NB4) & (kk < kend) & (n < g.Nld);
-            breg[j] = buf_load4(rwk, ok ? (unsigned)(kk * g.Nld + n) * 4u : kOOB);
+            breg[P][j] = buf_load4(rwk, ok ? (unsigned)(kk * g.Nld + n) * 4u : kOOB);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto set, int buf) {
+        constexpr int P = decltype(set)::value;
 #pragma unroll
-        for (int i = 0; i < AK; ++i) As[buf][akg * AK + i][am] = areg[i];
+        for (int i = 0; i < AK; ++i) As[buf][akg * AK + i][am] = areg[P][i];
 #pragma unroll
         for (int j = 0; j < BV; ++j)
-            if (BV * 256 == NB4 || tid + j * 256 < NB4) *reinterpret_cast<f32x4*>(&Bs[buf][bkr[j]][bnc[j]]) = breg[j];
+            if (BV * 256 == NB4 || tid + j * 256 < NB4) *reinterpret_cast<f32x4*>(&Bs[buf][bkr[j]][bnc[j]]) = breg[P][j];
     };
 
     f32x16 acc[TN][TM];
@@ -196,16 +201,12 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nkt > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
-    int buf = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) load_tile(kt + 1);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // one K tile: `cur` = register set that is free (tile kt already sits in LDS buffer `buf`), `nxt` = set holding tile kt+1
+    auto step = [&](auto cur, auto nxt, int kt, int buf) {
+        if (kt + 2 < nkt) load_tile(cur, kt + 2);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float av[TM], bv[TN];
@@ -219,9 +220,17 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[a], av[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+        if (kt + 1 < nkt) store_tile(nxt, buf ^ 1);
         __syncthreads();
-        buf ^= 1;
+    };
+
+    if (nkt > 0) load_tile(S0{}, 0);
+    if (nkt > 1) load_tile(S1{}, 1);
+    if (nkt > 0) store_tile(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        step(S0{}, S1{}, kt, 0);
+        if (kt + 1 < nkt) step(S1{}, S0{}, kt + 1, 1);
     }
 
     // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ---
@@ -250,31 +259,57 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const float* __res
     }
 }
 
-// out[i] = sum_s ws[s][i] (+ bias[channel])
+// out[i] = sum_s ws[s][i] (+ bias[channel]).  A workgroup covers 32 float4 elements x 8 split groups: each thread adds every
+// 8th slab (4 independent loads in flight), the 8 partial sums meet in LDS.  Deterministic (fixed summation order).
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
                                                         const float* __restrict__ bias, int C, int HW,
                                                         float* __restrict__ out) {
+    __shared__ float4 part[8][32];
     const size_t n4 = n / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 a = *reinterpret_cast<const float4*>(ws + i * 4);
-        for (int s = 1; s < nsplit; ++s) {
-            const float4 b = *reinterpret_cast<const float4*>(ws + (size_t)s * slab + i * 4);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < n4; base += (size_t)gridDim.x * 32) {
+        const size_t i = base + e;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            const float* p = ws + i * 4;
+            int sp = grp;
+            for (; sp + 24 < nsplit; sp += 32) {
+                const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)sp * slab);
+                const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 8) * slab);
+                const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 16) * slab);
+                const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 24) * slab);
+                a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+                a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+            }
+            for (; sp < nsplit; sp += 8) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sp * slab);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
         }
-        if (bias) {
-            const size_t e = i * 4;
-            a.x += bias[(e / HW) % C]; a.y += bias[((e + 1) / HW) % C];
-            a.z += bias[((e + 2) / HW) % C]; a.w += bias[((e + 3) / HW) % C];
+        part[grp][e] = a;
+        __syncthreads();
+        if (grp == 0 && i < n4) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const float4 v = part[k][e];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            if (bias) {
+                const size_t q = i * 4;
+                a.x += bias[(q / HW) % C]; a.y += bias[((q + 1) / HW) % C];
+                a.z += bias[((q + 2) / HW) % C]; a.w += bias[((q + 3) / HW) % C];
+            }
+            *reinterpret_cast<float4*>(out + i * 4) = a;
         }
-        *reinterpret_cast<float4*>(out + i * 4) = a;
+        __syncthreads();
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const size_t e = n4 * 4 + threadIdx.x;
+        const size_t q = n4 * 4 + threadIdx.x;
         float a = 0.f;
-        for (int s = 0; s < nsplit; ++s) a += ws[(size_t)s * slab + e];
-        if (bias) a += bias[(e / HW) % C];
-        out[e] = a;
+        for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * slab + q];
+        if (bias) a += bias[(q / HW) % C];
+        out[q] = a;
     }
 }
 
@@ -291,10 +326,10 @@ GatherPlan plan_gather(const Geom& g) {
     p.ncls = g.OS * g.OS;
     const int tiles = p.mtiles * p.ntiles * p.ncls;
     const int ktiles = cdiv(g.K, 16);
+    // fewer tiles than one round of resident workgroups (256 CUs x 3): split K so that the grid is one full round,
+    // never just over it (one block over a multiple of the slot count costs a whole extra round)
     int ks = 1;
-    if (tiles < 384) {
-        ks = std::min({cdiv(768, tiles), std::max(1, ktiles / 4), 32});
-    }
+    if (tiles < 768) ks = std::max(1, std::min({768 / tiles, std::max(1, ktiles / 4), 32}));
     p.kchunk = cdiv(ktiles, ks) * 16;
     p.ksplit = cdiv(g.K, p.kchunk);
     p.slab = (size_t)g.B * g.Cout * g.OH * g.OW;
@@ -339,9 +374,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     const int2* tk = ktab + i0 + wave * (BI / 4);          // this wave's 32 (BI=128) / 16 (BI=64) reduction rows: scalar loads
     const int nb = j0 + wave * (BJ / 4) + half;
 
-    float xreg[XR], yreg[YR];
+    float xreg[2][XR], yreg[2][YR];     // two pixel tiles in flight (see the gather kernel)
 
-    auto load_tile = [&](int pt) {
+    auto load_tile = [&](auto set, int pt) {
+        constexpr int P = decltype(set)::value;
         const int p = pbeg + pt * BP + pl;
         const bool pvalid = p < pend;
         const int pp = pvalid ? p : 0;
@@ -357,19 +393,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
             const int ex = half ? eb.x : ea.x, ey = half ? eb.y : ea.y;
             const int ddy = (int)(short)(ey & 0xFFFF), ddx = ey >> 16;
             const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
-            xreg[ii] = buf_load(rx, ok ? (unsigned)(pix0 + ex) * 4u : kOOB);
+            xreg[P][ii] = buf_load(rx, ok ? (unsigned)(pix0 + ex) * 4u : kOOB);
         }
 #pragma unroll
         for (int jj = 0; jj < YR; ++jj) {
             const int n = nb + 2 * jj;
-            yreg[jj] = buf_load(rdy, (pvalid & (n < g.Cout)) ? (unsigned)(dyoff + n * ohw) * 4u : kOOB);
+            yreg[P][jj] = buf_load(rdy, (pvalid & (n < g.Cout)) ? (unsigned)(dyoff + n * ohw) * 4u : kOOB);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto set, int buf) {
+        constexpr int P = decltype(set)::value;
 #pragma unroll
-        for (int ii = 0; ii < XR; ++ii) Xs[buf][wave * (BI / 4) + 2 * ii + half][pl] = xreg[ii];
+        for (int ii = 0; ii < XR; ++ii) Xs[buf][wave * (BI / 4) + 2 * ii + half][pl] = xreg[P][ii];
 #pragma unroll
-        for (int jj = 0; jj < YR; ++jj) Ys[buf][wave * (BJ / 4) + 2 * jj + half][pl] = yreg[jj];
+        for (int jj = 0; jj < YR; ++jj) Ys[buf][wave * (BJ / 4) + 2 * jj + half][pl] = yreg[P][jj];
     };
 
     f32x16 acc[TJ][TI];
@@ -380,15 +417,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (npt > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int pt = 0; pt < npt; ++pt) {
-        const bool more = pt + 1 < npt;
-        if (more) load_tile(pt + 1);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto step = [&](auto cur, auto nxt, int pt, int buf) {
+        if (pt + 2 < npt) load_tile(cur, pt + 2);
 #pragma unroll
         for (int pp = 0; pp < BP; pp += 2) {
             float av[TI], bv[TJ];
@@ -402,9 +434,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
                 for (int b = 0; b < TI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[a], av[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+        if (pt + 1 < npt) store_tile(nxt, buf ^ 1);
         __syncthreads();
-        buf ^= 1;
+    };
+
+    if (npt > 0) load_tile(S0{}, 0);
+    if (npt > 1) load_tile(S1{}, 1);
+    if (npt > 0) store_tile(S0{}, 0);
+    __syncthreads();
+    for (int pt = 0; pt < npt; pt += 2) {
+        step(S0{}, S1{}, pt, 0);
+        if (pt + 1 < npt) step(S1{}, S0{}, pt + 1, 1);
     }
 
     // D[cout][k index]: the lane owns one k column, so each register stores 32 consecutive floats of an OIHW row
@@ -437,8 +477,9 @@ WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     p.ncls = g.OS * g.OS;
     const int tiles = p.itiles * p.jtiles * p.ncls;
     const int ptiles = cdiv(g.Mtot, 32);
+    // split the pixel reduction so the grid is about two rounds of resident workgroups (256 CUs x 2), never one block over
     int ps = 1;
-    if (tiles < 1024) ps = std::min({cdiv(1024, tiles), std::max(1, ptiles / 4), 2048});
+    if (tiles < 1024) ps = std::max(1, std::min({1024 / tiles, std::max(1, ptiles / 4), 2048}));
     p.pchunk = cdiv(ptiles, ps) * 32;
     p.psplit = cdiv(g.Mtot, p.pchunk);
     p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
@@ -460,6 +501,53 @@ __device__ __host__ inline void up_fwd_taps(int p, int t, int& lo, int& hi) {
 __device__ __host__ inline void up_dgrad_taps(int t, int& lo, int& hi) {
     lo = 2 - t > 0 ? 2 - t : 0;
     hi = 3 - t < 2 ? 3 - t : 2;
+}
+
+// AGAN_PACK_FWD is a plain [cout][K] -> [K][Nld] transpose: 32x32 LDS tiles, coalesced on both sides.
+__global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + ty + j * 8, k = k0 + tx;
+        tile[ty + j * 8][tx] = (n < cout && k < K) ? w[(size_t)n * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + j * 8, n = n0 + tx;
+        if (k < K && n < Nld) wk[(size_t)k * Nld + n] = tile[tx][ty + j * 8];
+    }
+}
+
+// dgrad packs: wk[cls][(co, tap')][ci] = w[co][ci][tap(cls, tap')] -- per output channel co a [cin][T] -> [T'][cin] shuffle.
+// One workgroup stages a 64-input-channel slab of one co (64*T contiguous floats) in LDS and writes rows of 64 contiguous ci.
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin,
+                                                               int kh, int kw, int Nld) {
+    __shared__ float sl[64 * 16 + 64];
+    const int T = kh * kw;
+    const int co = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nc = min(64, cin - c0);
+    const float* src = w + ((size_t)co * cin + c0) * T;
+    for (int i = threadIdx.x; i < nc * T; i += 256) sl[(i / T) * (T + 1) + (i % T)] = src[i];   // +1 pad: column walks below
+    __syncthreads();
+    if (MODE == AGAN_PACK_DGRAD_S1) {
+        // K index = (co, r, s); source tap = flipped
+        for (int i = threadIdx.x; i < T * 64; i += 256) {
+            const int t = i / 64, c = i - t * 64;
+            if (c < nc) wk[((size_t)co * T + t) * Nld + c0 + c] = sl[c * (T + 1) + (T - 1 - t)];
+        }
+    } else {   // AGAN_PACK_DGRAD_4x4S2: 4 classes x (co, r, s in {0,1}); tap kh = ((py+1)&1) + 2r
+        const int K = cout * 4;
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+            const int q = i / 64, c = i - q * 64;
+            const int cls = q >> 2, r = (q >> 1) & 1, sx = q & 1, py = cls >> 1, px = cls & 1;
+            const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * sx;
+            if (c < nc) wk[((size_t)cls * K + co * 4 + r * 2 + sx) * Nld + c0 + c] = sl[c * 17 + th * 4 + tw];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wk, int mode,
@@ -579,6 +667,18 @@ int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int
     const int Nld = agan_round_up(N, 32);
     const size_t total = (size_t)ncls * K * Nld;
     const int blocks = (int)std::min<size_t>(cdivz(total, 256), 8192);
+    hipStream_t pst = as_stream(stream);
+    if (mode == AGAN_PACK_FWD) {
+        hipLaunchKernelGGL(pack_fwd_tiled_kernel, dim3(cdiv(K, 32), Nld / 32), dim3(256), 0, pst, w, wk, cout, K, Nld);
+        return check_launch("pack_weight/fwd");
+    }
+    if ((mode == AGAN_PACK_DGRAD_S1 && kh * kw <= 16) || mode == AGAN_PACK_DGRAD_4x4S2) {
+        if (Nld != cin) (void)hipMemsetAsync(wk, 0, total * sizeof(float), pst);      // zero the N padding columns
+        dim3 grid(cout, cdiv(cin, 64));
+        if (mode == AGAN_PACK_DGRAD_S1) hipLaunchKernelGGL((pack_dgrad_tiled_kernel<AGAN_PACK_DGRAD_S1>), grid, dim3(256), 0, pst, w, wk, cout, cin, kh, kw, Nld);
+        else hipLaunchKernelGGL((pack_dgrad_tiled_kernel<AGAN_PACK_DGRAD_4x4S2>), grid, dim3(256), 0, pst, w, wk, cout, cin, kh, kw, Nld);
+        return check_launch("pack_weight/dgrad");
+    }
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, wk, mode, cout, cin, kh, kw, K,
                        Nld, ncls);
     return check_launch("pack_weight");
@@ -624,7 +724,7 @@ int agan_conv_gather(const float* in, const float* wk, const float* bias, float*
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
-        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 256), 4096);
+        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
                            bias, g.Cout, g.OH * g.OW, out);
         return check_launch("conv_gather/sum_slabs");
@@ -668,7 +768,7 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     if (int e = check_launch("conv_wgrad")) return e;
     const size_t n = (size_t)p.ncls * g.Cout * g.K;
     if (p.psplit > 1) {
-        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 256), 4096);
+        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, p.psplit, n, p.slab, (const float*)nullptr, 1, 1, reduced);
         if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
     }
