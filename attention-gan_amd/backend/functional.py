@@ -110,18 +110,19 @@ def bump_weight_epoch() -> None:
 
 def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     cout, cin, kh, kw = w.shape
+    prec = _PRECISION[0]
     ver = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0], cout, cin, kh, kw)
-    hit = cache.get(mode) if cache is not None else None
+    hit = cache.get((mode, prec)) if cache is not None else None
     if hit is not None and hit[0] == ver:
         return hit[1]
-    n = L.load().agan_packed_weight_elems(mode, cout, cin, kh, kw)
+    n = L.load().agan_packed_weight_bytes(mode, cout, cin, kh, kw, prec)
     if n == 0:
-        raise L.AganError(f"pack mode {mode} does not take a {kh}x{kw} kernel")
+        raise L.AganError(f"pack mode {mode} / precision {prec} does not take a {kh}x{kw} kernel")
     reuse = hit is not None and hit[1].numel() == n and hit[1].device == w.device
-    wk = hit[1] if reuse else torch.empty(n, dtype=torch.float32, device=w.device)
-    L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, _stream())
+    wk = hit[1] if reuse else torch.empty(n, dtype=torch.uint8, device=w.device)
+    L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, prec, _stream())
     if cache is not None:
-        cache[mode] = (ver, wk)
+        cache[(mode, prec)] = (ver, wk)
     return wk
 
 
@@ -150,7 +151,7 @@ def set_launch_observer(obs) -> None:
 
 def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "") -> None:
     lib = L.load()
-    nbytes = lib.agan_conv_gather_ws_bytes(byref(g))
+    nbytes = lib.agan_conv_gather_ws_bytes(byref(g), _PRECISION[0])
     ws, wsp = _ws(nbytes, x)
     kt = ktable(g, x.device)
     obs = _OBSERVER[0]

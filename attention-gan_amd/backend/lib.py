@@ -30,9 +30,9 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "agan_version": (c_int, []),
     "agan_last_error": (c_char_p, []),
-    "agan_packed_weight_elems": (c_size_t, [c_int] * 5),
-    "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
+    "agan_packed_weight_bytes": (c_size_t, [c_int] * 6),
+    "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
     "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, _P, c_size_t, _P]),

@@ -10,65 +10,14 @@
 // lanes 0..31 read 32 consecutive floats and lanes 32..63 the next k row.
 // The MFMA is issued as D[cout][pixel] (weights as the A operand) so that every accumulator register holds
 // 32 consecutive pixels of one output channel: NCHW stores are 128-B coalesced.
-#include "agan_common.h"
+#include "conv_common.h"
 
-#include <algorithm>
-#include <type_traits>
 
 using namespace agan;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace agan::conv;
 
 namespace {
-
-// n / d for n < 2^31 by multiply-high (Granlund-Montgomery round-up form): 2 VALU ops instead of a ~40-instruction sequence
-struct FastDiv {
-    unsigned mul, shift;
-    __device__ __forceinline__ int div(int n) const { return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> shift); }
-};
-FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.shift = l;
-    return f;
-}
-
-struct Geom {
-    int B, Cin, IH, IW, Cout, OH, OW, R, S, OS, SY, DY, OY0, OY1;
-    int OHs, OWs, HWs, Mtot, K, Nld, RS;
-    FastDiv dHWs, dOWs;
-};
-
-// Reduction-index table: entry k = (ci, r, s) -> { element offset ci*IH*IW + r*DY*IW + s*DY , packed (dy = r*DY, dx = s*DY) }.
-// Built once per geometry (agan_conv_ktable) and read with scalar loads, so the kernels spend no ALU work on decoding k.
-// Entries >= K are sentinels whose dy fails every range check.
-constexpr int kTabPad = 128;
-constexpr int kSentinelDy = -32768;
-__host__ __device__ inline int ktable_entries(int K) { return (K + kTabPad - 1) / kTabPad * kTabPad + kTabPad; }
-
-Geom make_geom(const agan_conv_geom* g) {
-    Geom d;
-    d.B = g->B; d.Cin = g->Cin; d.IH = g->IH; d.IW = g->IW; d.Cout = g->Cout; d.OH = g->OH; d.OW = g->OW;
-    d.R = g->R; d.S = g->S; d.OS = g->OS; d.SY = g->SY; d.DY = g->DY; d.OY0 = g->OY[0]; d.OY1 = g->OY[1];
-    d.OHs = g->OH / g->OS; d.OWs = g->OW / g->OS; d.HWs = d.OHs * d.OWs; d.Mtot = g->B * d.HWs;
-    d.RS = g->R * g->S; d.K = g->Cin * d.RS; d.Nld = agan_round_up(g->Cout, 32);
-    d.dHWs = make_fastdiv((unsigned)d.HWs); d.dOWs = make_fastdiv((unsigned)d.OWs);
-    return d;
-}
-
-int check_geom(const agan_conv_geom* g) {
-    AGAN_REQUIRE(g != nullptr, "conv: null geometry");
-    AGAN_REQUIRE(g->B > 0 && g->Cin > 0 && g->IH > 0 && g->IW > 0 && g->Cout > 0 && g->OH > 0 && g->OW > 0,
-                 "conv: non-positive dimension");
-    AGAN_REQUIRE(g->R > 0 && g->S > 0 && g->R <= 8 && g->S <= 8, "conv: taps %dx%d unsupported", g->R, g->S);
-    AGAN_REQUIRE(g->OS == 1 || g->OS == 2, "conv: OS must be 1 or 2");
-    AGAN_REQUIRE(g->OH % g->OS == 0 && g->OW % g->OS == 0, "conv: OH/OW not divisible by OS");
-    const long long in_elems = 1LL * g->B * g->Cin * g->IH * g->IW, out_elems = 1LL * g->B * g->Cout * g->OH * g->OW;
-    AGAN_REQUIRE(in_elems < (1LL << 30) && out_elems < (1LL << 30), "conv: tensor exceeds 2^30 elements (32-bit buffer offsets)");
-    return AGAN_OK;
-}
 
 __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int n, int K, int RS, int S, int IHW, int IW, int DY) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -84,24 +33,6 @@ __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int
         e.y = kSentinelDy & 0xFFFF;
     }
     tab[k] = e;
-}
-
-// Raw buffer resources: the hardware range check turns every out-of-image / out-of-tile access into a zero load
-// (or a dropped store) -- no exec-mask branches around the gathers (cdna_hip_programming.md T8).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0xFFFFFFFFu;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
 // ================================================================================================
@@ -169,13 +100,21 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
     auto load_tile = [&](auto set, int kt) {
         constexpr int P = decltype(set)::value;
         const int kb = kbeg + kt * BK;
-        const int2* tk = ktab + kb + akg * AK;          // wave-uniform -> scalar loads
+        // this wave's AK table entries in one wide scalar load (wave-uniform address, 16-byte aligned)
+        const int4* tk4 = reinterpret_cast<const int4*>(ktab + kb + akg * AK);
+        int te[2 * AK];
+#pragma unroll
+        for (int i = 0; i < AK / 2; ++i) {
+            const int4 q = tk4[i];
+            te[4 * i] = q.x; te[4 * i + 1] = q.y; te[4 * i + 2] = q.z; te[4 * i + 3] = q.w;
+        }
 #pragma unroll
         for (int i = 0; i < AK; ++i) {
-            const int2 e = tk[i];
-            const int dy = (int)(short)(e.y & 0xFFFF), dx = e.y >> 16;
+            const int ex = te[2 * i], ey = te[2 * i + 1];
+            const int dy = (int)(short)(ey & 0xFFFF), dx = ey >> 16;
             const bool ok = ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
-            areg[P][i] = buf_load(rin, ok ? (unsigned)(pix0 + e.x) * 4u : kOOB);
+            const unsigned off = (unsigned)(pix0 + ex) * 4u;
+            areg[P][i] = buf_load(rin, ok ? off : kOOB);
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
@@ -207,18 +146,26 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
     // one K tile: `cur` = register set that is free (tile kt already sits in LDS buffer `buf`), `nxt` = set holding tile kt+1
     auto step = [&](auto cur, auto nxt, int kt, int buf) {
         if (kt + 2 < nkt) load_tile(cur, kt + 2);
+        // operand fragments are read one k-step ahead of the MFMAs that consume them (LDS latency off the critical path)
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) av[0][t] = As[buf][lh][wm * WTM + t * 32 + l31];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bv[0][t] = Bs[buf][lh][wn * WTN + t * 32 + l31];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
+            const int c = (kk >> 1) & 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) av[t] = As[buf][kk + lh][wm * WTM + t * 32 + l31];
+                for (int t = 0; t < TM; ++t) av[c ^ 1][t] = As[buf][kk + 2 + lh][wm * WTM + t * 32 + l31];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bv[t] = Bs[buf][kk + lh][wn * WTN + t * 32 + l31];
+                for (int t = 0; t < TN; ++t) bv[c ^ 1][t] = Bs[buf][kk + 2 + lh][wn * WTN + t * 32 + l31];
+            }
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[a], av[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][a], av[c][b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < nkt) store_tile(nxt, buf ^ 1);
         __syncthreads();
@@ -313,31 +260,6 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     }
 }
 
-struct GatherPlan {
-    int bn, mtiles, ntiles, ncls, ksplit, kchunk;
-    size_t slab, ws_bytes;
-};
-
-GatherPlan plan_gather(const Geom& g) {
-    GatherPlan p;
-    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
-    p.mtiles = cdiv(g.Mtot, 128);
-    p.ntiles = cdiv(g.Cout, p.bn);
-    p.ncls = g.OS * g.OS;
-    const int tiles = p.mtiles * p.ntiles * p.ncls;
-    const int ktiles = cdiv(g.K, 16);
-    // fewer tiles than one round of resident workgroups (256 CUs x 3): split K so that the grid is one full round,
-    // never just over it (one block over a multiple of the slot count costs a whole extra round)
-    int ks = 1;
-    if (tiles < 768) ks = std::max(1, std::min({768 / tiles, std::max(1, ktiles / 4), 32}));
-    p.kchunk = cdiv(ktiles, ks) * 16;
-    p.ksplit = cdiv(g.K, p.kchunk);
-    p.slab = (size_t)g.B * g.Cout * g.OH * g.OW;
-    p.slab = (p.slab + 3) / 4 * 4;   // keep every slab 16-B aligned
-    p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
-    return p;
-}
-
 template <int BN, int WM, int WN>
 void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
                    const GatherPlan& p, hipStream_t st) {
@@ -371,7 +293,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
-    const int2* tk = ktab + i0 + wave * (BI / 4);          // this wave's 32 (BI=128) / 16 (BI=64) reduction rows: scalar loads
+    // the reduction rows this thread stages never change across the pixel loop: fetch their table entries once
+    int tex[XR], tey[XR];
+#pragma unroll
+    for (int ii = 0; ii < XR; ++ii) {
+        const int2 e = ktab[i0 + wave * (BI / 4) + 2 * ii + half];
+        tex[ii] = e.x;
+        tey[ii] = e.y;
+    }
     const int nb = j0 + wave * (BJ / 4) + half;
 
     float xreg[2][XR], yreg[2][YR];     // two pixel tiles in flight (see the gather kernel)
@@ -389,11 +318,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         const int dyoff = b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px);
 #pragma unroll
         for (int ii = 0; ii < XR; ++ii) {
-            const int2 ea = tk[2 * ii], eb = tk[2 * ii + 1];
-            const int ex = half ? eb.x : ea.x, ey = half ? eb.y : ea.y;
-            const int ddy = (int)(short)(ey & 0xFFFF), ddx = ey >> 16;
+            const int ddy = (int)(short)(tey[ii] & 0xFFFF), ddx = tey[ii] >> 16;
             const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
-            xreg[P][ii] = buf_load(rx, ok ? (unsigned)(pix0 + ex) * 4u : kOOB);
+            const unsigned off = (unsigned)(pix0 + tex[ii]) * 4u;
+            xreg[P][ii] = buf_load(rx, ok ? off : kOOB);
         }
 #pragma unroll
         for (int jj = 0; jj < YR; ++jj) {
@@ -421,18 +349,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     using S1 = std::integral_constant<int, 1>;
     auto step = [&](auto cur, auto nxt, int pt, int buf) {
         if (pt + 2 < npt) load_tile(cur, pt + 2);
+        float av[2][TI], bv[2][TJ];
+#pragma unroll
+        for (int t = 0; t < TI; ++t) av[0][t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][half];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) bv[0][t] = Ys[buf][wj * (BJ / 2) + t * 32 + pl][half];
 #pragma unroll
         for (int pp = 0; pp < BP; pp += 2) {
-            float av[TI], bv[TJ];
+            const int c = (pp >> 1) & 1;
+            if (pp + 2 < BP) {
 #pragma unroll
-            for (int t = 0; t < TI; ++t) av[t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][pp + half];
+                for (int t = 0; t < TI; ++t) av[c ^ 1][t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][pp + 2 + half];
 #pragma unroll
-            for (int t = 0; t < TJ; ++t) bv[t] = Ys[buf][wj * (BJ / 2) + t * 32 + pl][pp + half];
+                for (int t = 0; t < TJ; ++t) bv[c ^ 1][t] = Ys[buf][wj * (BJ / 2) + t * 32 + pl][pp + 2 + half];
+            }
 #pragma unroll
             for (int a = 0; a < TJ; ++a)
 #pragma unroll
                 for (int b = 0; b < TI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[a], av[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][a], av[c][b], acc[a][b], 0, 0, 0);
         }
         if (pt + 1 < npt) store_tile(nxt, buf ^ 1);
         __syncthreads();
@@ -463,46 +398,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         }
 }
 
-struct WgradPlan {
-    int bi, bj, itiles, jtiles, ncls, psplit, pchunk;
-    size_t slab, ws_bytes;
-};
-
-WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
-    WgradPlan p;
-    p.bi = g.K >= 96 ? 128 : 64;
-    p.bj = g.Cout >= 96 ? 128 : 64;
-    p.itiles = cdiv(g.K, p.bi);
-    p.jtiles = cdiv(g.Cout, p.bj);
-    p.ncls = g.OS * g.OS;
-    const int tiles = p.itiles * p.jtiles * p.ncls;
-    const int ptiles = cdiv(g.Mtot, 32);
-    // split the pixel reduction so the grid is about two rounds of resident workgroups (256 CUs x 2), never one block over
-    int ps = 1;
-    if (tiles < 1024) ps = std::max(1, std::min({1024 / tiles, std::max(1, ptiles / 4), 2048}));
-    p.pchunk = cdiv(ptiles, ps) * 32;
-    p.psplit = cdiv(g.Mtot, p.pchunk);
-    p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
-    // partial slabs (only when split) + one reduced slab when a tap-combine pass follows
-    const size_t nslabs = (p.psplit > 1 ? p.psplit : 0) + (needs_combine ? 1 : 0);
-    p.ws_bytes = p.slab * nslabs * sizeof(float);
-    return p;
-}
-
 // ================================================================================================
 // weight packing (OIHW -> [cls][K][Nld]) and gradient unpacking ([split][cls][K][Nld] -> OIHW)
 // ================================================================================================
-// which 3x3 taps fold into tap t' of parity class p for Upsample(x2)+conv3x3:  p=0: {0},{1,2}; p=1: {0,1},{2}
-__device__ __host__ inline void up_fwd_taps(int p, int t, int& lo, int& hi) {
-    if (p == 0) { lo = t == 0 ? 0 : 1; hi = t == 0 ? 0 : 2; }
-    else        { lo = t == 0 ? 0 : 2; hi = t == 0 ? 1 : 2; }
-}
-// which 3x3 taps fold into tap t (0..3) of the 4x4 s2 dgrad kernel: {2},{1,2},{0,1},{0}
-__device__ __host__ inline void up_dgrad_taps(int t, int& lo, int& hi) {
-    lo = 2 - t > 0 ? 2 - t : 0;
-    hi = 3 - t < 2 ? 3 - t : 2;
-}
-
 // AGAN_PACK_FWD is a plain [cout][K] -> [K][Nld] transpose: 32x32 LDS tiles, coalesced on both sides.
 __global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld) {
     __shared__ float tile[32][33];
@@ -558,42 +456,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const int n = (int)(e % Nld);
         const size_t t = e / Nld;
         const int k = (int)(t % K), cls = (int)(t / K);
-        float v = 0.f;
-        if (mode == AGAN_PACK_FWD) {
-            if (n < cout) v = w[(size_t)n * K + k];
-        } else if (mode == AGAN_PACK_DGRAD_S1) {
-            // k = (co, r, s), n = ci
-            const int khw = kh * kw, co = k / khw, rs = k - co * khw, r = rs / kw, s = rs - r * kw;
-            if (n < cin) v = w[(((size_t)co * cin + n) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)];
-        } else if (mode == AGAN_PACK_DGRAD_4x4S2) {
-            // cls = (py,px); k = (co, r, s) with r,s in {0,1}; n = ci; tap kh = ((py+1)&1) + 2r
-            const int py = cls >> 1, px = cls & 1, co = k >> 2, r = (k >> 1) & 1, s = k & 1;
-            const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * s;
-            if (n < cin) v = w[(((size_t)co * cin + n) * 4 + th) * 4 + tw];
-        } else if (mode == AGAN_PACK_UP_FWD) {
-            // cls = (py,px); k = (ci, r', s'); n = co
-            const int py = cls >> 1, px = cls & 1, ci = k >> 2, r = (k >> 1) & 1, s = k & 1;
-            if (n < cout) {
-                int rl, rh, sl, sh;
-                up_fwd_taps(py, r, rl, rh);
-                up_fwd_taps(px, s, sl, sh);
-                const float* wp = w + ((size_t)n * cin + ci) * 9;
-                for (int a = rl; a <= rh; ++a)
-                    for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
-            }
-        } else if (mode == AGAN_PACK_UP_DGRAD) {
-            // k = (co, t, u) with t,u in 0..3; n = ci
-            const int co = k >> 4, t = (k >> 2) & 3, u = k & 3;
-            if (n < cin) {
-                int rl, rh, sl, sh;
-                up_dgrad_taps(t, rl, rh);
-                up_dgrad_taps(u, sl, sh);
-                const float* wp = w + ((size_t)co * cin + n) * 9;
-                for (int a = rl; a <= rh; ++a)
-                    for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
-            }
-        }
-        wk[e] = v;
+        wk[e] = packed_weight_value(w, mode, cls, k, n, cout, cin, kh, kw);
     }
 }
 
@@ -636,17 +499,6 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (threadIdx.x == 0) db[c] = s;
 }
 
-int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, int& N) {
-    switch (mode) {
-        case AGAN_PACK_FWD: ncls = 1; K = cin * kh * kw; N = cout; return 0;
-        case AGAN_PACK_DGRAD_S1: ncls = 1; K = cout * kh * kw; N = cin; return 0;
-        case AGAN_PACK_DGRAD_4x4S2: if (kh != 4 || kw != 4) return -1; ncls = 4; K = cout * 4; N = cin; return 0;
-        case AGAN_PACK_UP_FWD: if (kh != 3 || kw != 3) return -1; ncls = 4; K = cin * 4; N = cout; return 0;
-        case AGAN_PACK_UP_DGRAD: if (kh != 3 || kw != 3) return -1; ncls = 1; K = cout * 16; N = cin; return 0;
-    }
-    return -1;
-}
-
 }  // namespace
 
 // ================================================================================================
@@ -654,15 +506,23 @@ int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, in
 // ================================================================================================
 extern "C" {
 
-size_t agan_packed_weight_elems(int mode, int cout, int cin, int kh, int kw) {
+size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec) {
     int ncls, K, N;
     if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
-    return (size_t)ncls * K * agan_round_up(N, 32);
+    if (prec == AGAN_PREC_F32) return (size_t)ncls * K * agan_round_up(N, 32) * sizeof(float);
+    if (prec == AGAN_PREC_BF16X3) return (size_t)ncls * 2 * agan_round_up(N, 32) * agan_round_up(K, 32) * sizeof(unsigned short);
+    return 0;
 }
 
-int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int kh, int kw, void* stream) {
+int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int kh, int kw, int prec, void* stream) {
     int ncls, K, N;
-    AGAN_REQUIRE(w && wk, "pack_weight: null pointer");
+    AGAN_REQUIRE(w && wkv, "pack_weight: null pointer");
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "pack_weight: precision mode %d not built", prec);
+    if (prec == AGAN_PREC_BF16X3) {
+        AGAN_REQUIRE(pack_dims(mode, cout, cin, kh, kw, ncls, K, N) == 0, "pack_weight: mode %d does not take %dx%d", mode, kh, kw);
+        return pack_weight_bf16x3(w, wkv, mode, cout, cin, kh, kw, as_stream(stream));
+    }
+    float* wk = static_cast<float*>(wkv);
     AGAN_REQUIRE(pack_dims(mode, cout, cin, kh, kw, ncls, K, N) == 0, "pack_weight: mode %d does not take %dx%d", mode, kh, kw);
     const int Nld = agan_round_up(N, 32);
     const size_t total = (size_t)ncls * K * Nld;
@@ -684,9 +544,9 @@ int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int
     return check_launch("pack_weight");
 }
 
-size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g) {
+size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (check_geom(g)) return 0;
-    return plan_gather(make_geom(g)).ws_bytes;
+    return plan_gather(make_geom(g), prec).ws_bytes;
 }
 
 size_t agan_conv_ktable_elems(const agan_conv_geom* g) {
@@ -704,21 +564,23 @@ int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
     return check_launch("conv_ktable");
 }
 
-int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
+int agan_conv_gather(const float* in, const void* wkv, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
                      int prec, void* ws, size_t ws_bytes, void* stream) {
+    const float* wk = static_cast<const float*>(wkv);
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
-    AGAN_REQUIRE(prec == AGAN_PREC_F32, "conv_gather: precision mode %d not built in this version", prec);
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_gather: precision mode %d not built in this version", prec);
     const Geom g = make_geom(gg);
-    const GatherPlan p = plan_gather(g);
+    const GatherPlan p = plan_gather(g, prec);
     if (p.ws_bytes > ws_bytes || (p.ws_bytes && !ws)) {
         set_error("conv_gather: workspace %zu < %zu", ws_bytes, p.ws_bytes);
         return AGAN_EWORKSPACE;
     }
     hipStream_t st = as_stream(stream);
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
-    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
+    if (prec == AGAN_PREC_BF16X3) launch_gather_bf16x3(in, wkv, bias, dst, ktab, g, p, st);
+    else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
     else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
     else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, st);
     if (int e = check_launch("conv_gather")) return e;
@@ -741,7 +603,7 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
                     int kh, int kw, int prec, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
-    AGAN_REQUIRE(prec == AGAN_PREC_F32, "conv_wgrad: precision mode %d not built in this version", prec);
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_wgrad: precision mode %d not built in this version", prec);
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
     const bool up = pack_mode == AGAN_PACK_UP_FWD;
@@ -760,7 +622,8 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     float* part = p.psplit > 1 ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
 #define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab)
-    if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
+    if (prec == AGAN_PREC_BF16X3) launch_wgrad_bf16x3(x, dy, part, ktab, g, p, st);
+    else if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
     else if (p.bi == 128) AGAN_WG(128, 64);
     else if (p.bj == 128) AGAN_WG(64, 128);
     else AGAN_WG(64, 64);

@@ -1,0 +1,206 @@
+// Shared pieces of the convolution engine (geometry, reduction-index table, raw-buffer access, tap folding, launch plans).
+#pragma once
+#include "agan_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace agan {
+namespace conv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+// n / d for n < 2^31 by multiply-high (Granlund-Montgomery round-up form): 2 VALU ops instead of a ~40-instruction sequence
+struct FastDiv {
+    unsigned mul, shift;
+    __device__ __forceinline__ int div(int n) const { return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> shift); }
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.shift = l;
+    return f;
+}
+
+struct Geom {
+    int B, Cin, IH, IW, Cout, OH, OW, R, S, OS, SY, DY, OY0, OY1;
+    int OHs, OWs, HWs, Mtot, K, Nld, RS;
+    FastDiv dHWs, dOWs;
+};
+
+// Reduction-index table: entry k = (ci, r, s) -> { element offset ci*IH*IW + r*DY*IW + s*DY , packed (dy = r*DY, dx = s*DY) }.
+// Built once per geometry (agan_conv_ktable) and read with scalar loads, so the kernels spend no ALU work on decoding k.
+// Entries >= K are sentinels whose dy fails every range check.
+constexpr int kTabPad = 128;
+constexpr int kSentinelDy = -32768;
+__host__ __device__ inline int ktable_entries(int K) { return (K + kTabPad - 1) / kTabPad * kTabPad + kTabPad; }
+
+inline Geom make_geom(const agan_conv_geom* g) {
+    Geom d;
+    d.B = g->B; d.Cin = g->Cin; d.IH = g->IH; d.IW = g->IW; d.Cout = g->Cout; d.OH = g->OH; d.OW = g->OW;
+    d.R = g->R; d.S = g->S; d.OS = g->OS; d.SY = g->SY; d.DY = g->DY; d.OY0 = g->OY[0]; d.OY1 = g->OY[1];
+    d.OHs = g->OH / g->OS; d.OWs = g->OW / g->OS; d.HWs = d.OHs * d.OWs; d.Mtot = g->B * d.HWs;
+    d.RS = g->R * g->S; d.K = g->Cin * d.RS; d.Nld = agan_round_up(g->Cout, 32);
+    d.dHWs = make_fastdiv((unsigned)d.HWs); d.dOWs = make_fastdiv((unsigned)d.OWs);
+    return d;
+}
+
+inline int check_geom(const agan_conv_geom* g) {
+    AGAN_REQUIRE(g != nullptr, "conv: null geometry");
+    AGAN_REQUIRE(g->B > 0 && g->Cin > 0 && g->IH > 0 && g->IW > 0 && g->Cout > 0 && g->OH > 0 && g->OW > 0,
+                 "conv: non-positive dimension");
+    AGAN_REQUIRE(g->R > 0 && g->S > 0 && g->R <= 8 && g->S <= 8, "conv: taps %dx%d unsupported", g->R, g->S);
+    AGAN_REQUIRE(g->OS == 1 || g->OS == 2, "conv: OS must be 1 or 2");
+    AGAN_REQUIRE(g->OH % g->OS == 0 && g->OW % g->OS == 0, "conv: OH/OW not divisible by OS");
+    const long long in_elems = 1LL * g->B * g->Cin * g->IH * g->IW, out_elems = 1LL * g->B * g->Cout * g->OH * g->OW;
+    AGAN_REQUIRE(in_elems < (1LL << 30) && out_elems < (1LL << 30), "conv: tensor exceeds 2^30 elements (32-bit buffer offsets)");
+    return AGAN_OK;
+}
+
+// Raw buffer resources: the hardware range check turns every out-of-image / out-of-tile access into a zero load
+// (or a dropped store) -- no exec-mask branches around the gathers (cdna_hip_programming.md T8).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// which 3x3 taps fold into tap t' of parity class p for Upsample(x2)+conv3x3:  p=0: {0},{1,2}; p=1: {0,1},{2}
+__device__ __host__ inline void up_fwd_taps(int p, int t, int& lo, int& hi) {
+    if (p == 0) { lo = t == 0 ? 0 : 1; hi = t == 0 ? 0 : 2; }
+    else        { lo = t == 0 ? 0 : 2; hi = t == 0 ? 1 : 2; }
+}
+// which 3x3 taps fold into tap t (0..3) of the 4x4 s2 dgrad kernel: {2},{1,2},{0,1},{0}
+__device__ __host__ inline void up_dgrad_taps(int t, int& lo, int& hi) {
+    lo = 2 - t > 0 ? 2 - t : 0;
+    hi = 3 - t < 2 ? 3 - t : 2;
+}
+
+
+// Value of packed-weight element (class cls, reduction index k, output column n) for each agan_pack_weight mode (0 = padding).
+__device__ inline float packed_weight_value(const float* __restrict__ w, int mode, int cls, int k, int n, int cout, int cin, int kh, int kw) {
+    float v = 0.f;
+    if (mode == AGAN_PACK_FWD) {
+        const int K = cin * kh * kw;
+        if (n < cout) v = w[(size_t)n * K + k];
+    } else if (mode == AGAN_PACK_DGRAD_S1) {
+        // k = (co, r, s), n = ci
+        const int khw = kh * kw, co = k / khw, rs = k - co * khw, r = rs / kw, s = rs - r * kw;
+        if (n < cin) v = w[(((size_t)co * cin + n) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)];
+    } else if (mode == AGAN_PACK_DGRAD_4x4S2) {
+        // cls = (py,px); k = (co, r, s) with r,s in {0,1}; n = ci; tap kh = ((py+1)&1) + 2r
+        const int py = cls >> 1, px = cls & 1, co = k >> 2, r = (k >> 1) & 1, s = k & 1;
+        const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * s;
+        if (n < cin) v = w[(((size_t)co * cin + n) * 4 + th) * 4 + tw];
+    } else if (mode == AGAN_PACK_UP_FWD) {
+        // cls = (py,px); k = (ci, r', s'); n = co
+        const int py = cls >> 1, px = cls & 1, ci = k >> 2, r = (k >> 1) & 1, s = k & 1;
+        if (n < cout) {
+            int rl, rh, sl, sh;
+            up_fwd_taps(py, r, rl, rh);
+            up_fwd_taps(px, s, sl, sh);
+            const float* wp = w + ((size_t)n * cin + ci) * 9;
+            for (int a = rl; a <= rh; ++a)
+                for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
+        }
+    } else if (mode == AGAN_PACK_UP_DGRAD) {
+        // k = (co, t, u) with t,u in 0..3; n = ci
+        const int co = k >> 4, t = (k >> 2) & 3, u = k & 3;
+        if (n < cin) {
+            int rl, rh, sl, sh;
+            up_dgrad_taps(t, rl, rh);
+            up_dgrad_taps(u, sl, sh);
+            const float* wp = w + ((size_t)co * cin + n) * 9;
+            for (int a = rl; a <= rh; ++a)
+                for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
+        }
+    }
+    return v;
+}
+
+inline int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, int& N) {
+    switch (mode) {
+        case AGAN_PACK_FWD: ncls = 1; K = cin * kh * kw; N = cout; return 0;
+        case AGAN_PACK_DGRAD_S1: ncls = 1; K = cout * kh * kw; N = cin; return 0;
+        case AGAN_PACK_DGRAD_4x4S2: if (kh != 4 || kw != 4) return -1; ncls = 4; K = cout * 4; N = cin; return 0;
+        case AGAN_PACK_UP_FWD: if (kh != 3 || kw != 3) return -1; ncls = 4; K = cin * 4; N = cout; return 0;
+        case AGAN_PACK_UP_DGRAD: if (kh != 3 || kw != 3) return -1; ncls = 1; K = cout * 16; N = cin; return 0;
+    }
+    return -1;
+}
+
+// ---- launch plans ------------------------------------------------------------------------------------------------
+struct GatherPlan {
+    int bn, mtiles, ntiles, ncls, ksplit, kchunk;
+    size_t slab, ws_bytes;
+};
+
+inline GatherPlan plan_gather(const Geom& g, int prec) {
+    const int bk = prec == AGAN_PREC_F32 ? 16 : 32;              // K tile of the kernel family
+    const int slots = prec == AGAN_PREC_F32 ? 768 : 512;         // resident workgroups per round: 256 CUs x 3 (f32) / x 2 (bf16x3)
+    GatherPlan p;
+    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
+    p.mtiles = cdiv(g.Mtot, 128);
+    p.ntiles = cdiv(g.Cout, p.bn);
+    p.ncls = g.OS * g.OS;
+    const int tiles = p.mtiles * p.ntiles * p.ncls;
+    const int ktiles = cdiv(g.K, bk);
+    // fewer tiles than one round of resident workgroups: split K so that the grid is one full round, never just over it
+    // (one block over a multiple of the slot count costs a whole extra round)
+    int ks = 1;
+    if (tiles < slots) ks = std::max(1, std::min({slots / tiles, std::max(1, ktiles / 4), 32}));
+    p.kchunk = cdiv(ktiles, ks) * bk;
+    p.ksplit = cdiv(g.K, p.kchunk);
+    p.slab = (size_t)g.B * g.Cout * g.OH * g.OW;
+    p.slab = (p.slab + 3) / 4 * 4;   // keep every slab 16-B aligned
+    p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
+    return p;
+}
+
+struct WgradPlan {
+    int bi, bj, itiles, jtiles, ncls, psplit, pchunk;
+    size_t slab, ws_bytes;
+};
+
+inline WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
+    WgradPlan p;
+    p.bi = g.K >= 96 ? 128 : 64;
+    p.bj = g.Cout >= 96 ? 128 : 64;
+    p.itiles = cdiv(g.K, p.bi);
+    p.jtiles = cdiv(g.Cout, p.bj);
+    p.ncls = g.OS * g.OS;
+    const int tiles = p.itiles * p.jtiles * p.ncls;
+    const int ptiles = cdiv(g.Mtot, 32);
+    // split the pixel reduction so the grid is about two rounds of resident workgroups (256 CUs x 2), never one block over
+    int ps = 1;
+    if (tiles < 1024) ps = std::max(1, std::min({1024 / tiles, std::max(1, ptiles / 4), 2048}));
+    p.pchunk = cdiv(ptiles, ps) * 32;
+    p.psplit = cdiv(g.Mtot, p.pchunk);
+    p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
+    // partial slabs (only when split) + one reduced slab when a tap-combine pass follows
+    const size_t nslabs = (p.psplit > 1 ? p.psplit : 0) + (needs_combine ? 1 : 0);
+    p.ws_bytes = p.slab * nslabs * sizeof(float);
+    return p;
+}
+
+// AGAN_PREC_BF16X3 kernels (conv_bf16.hip)
+int pack_weight_bf16x3(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, hipStream_t st);
+void launch_gather_bf16x3(const float* in, const void* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
+                          const GatherPlan& p, hipStream_t st);
+void launch_wgrad_bf16x3(const float* x, const float* dy, float* part, const int2* ktab, const Geom& g, const WgradPlan& p, hipStream_t st);
+
+}  // namespace conv
+}  // namespace agan

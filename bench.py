@@ -27,7 +27,9 @@ if ROOT not in sys.path:
 
 # hyper-parameters of the metric configuration (train.py:34-49; BASELINE.json configs[2])
 GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
-F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (spec): f32 = v_mfma_f32_32x32x2_f32; bf16x3 is priced against the
+# bf16 peak although it issues three MFMAs per algorithmic product (its fraction can therefore not exceed 1/3)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}
 
 
 def algorithmic_conv_flops(kind, B, Cin, H, W, Cout, k):
@@ -46,8 +48,8 @@ class ConvTimer:
     """HIP-event pairs around every conv-engine launch (the events go on torch's current stream, which is the stream the
     kernels are enqueued on); durations are read after the timed region has been synchronised."""
 
-    def __init__(self):
-        self.records, self.enabled, self._open = [], False, None
+    def __init__(self, mode="f32"):
+        self.records, self.enabled, self._open, self.mode = [], False, None, mode
 
     def begin(self, kind, phase, g):
         if not self.enabled:
@@ -58,7 +60,7 @@ class ConvTimer:
         # the folded kernels (fwd: 4 classes x 2x2 taps; dgrad: 4x4 s2; wgrad: 4 classes) execute 4/9 of that.
         algorithmic = executed * (9.0 / 4.0) if kind == "up" else executed
         tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
-        name = f"conv_wgrad_f32" if phase == "wgrad" else f"conv_gather_f32_{tile}"
+        name = f"conv_wgrad_{self.mode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         self._open = (name, algorithmic, executed, e0)
@@ -132,6 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+                    help="MFMA mode of the conv engine: f32 = exact fp32 products (parity mode, default); bf16x3 = 3-term bf16 split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     args = ap.parse_args()
@@ -150,9 +154,11 @@ def main():
     dev = torch.device("cuda", local)
 
     HF = importlib.import_module("attention-gan_amd.backend.functional")
+    LIB = importlib.import_module("attention-gan_amd.backend.lib")
+    HF.set_precision(LIB.PREC_F32 if args.precision == "f32" else LIB.PREC_BF16X3)
     step = build(dev, args.batch, HF)
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
-    timer = ConvTimer()
+    timer = ConvTimer(args.precision)
     HF.set_launch_observer(timer)
 
     def one_step():
@@ -187,8 +193,9 @@ def main():
         if dom:
             name, (n, ms, falg, fexec) = dom
             achieved = falg / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            peak = MFMA_PEAK_TFLOPS[args.precision]
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),
                         "share_of_step_time": round(ms / (elapsed * 1e3), 3)}
         line = {
@@ -196,7 +203,7 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "full 3-stage AttnGAN 64->128->256 train step: G + 3xD updates + word attention + DAMSM words/sentence "
                                    "loss + KL + 4x fused Adam (BASELINE.json configs[2])",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "gf_dim": GF, "df_dim": DF, "emb_dim": EMB,

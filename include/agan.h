@@ -37,7 +37,7 @@ enum {
 /* arithmetic mode of the MFMA contractions (fp32 storage everywhere, fp32 accumulate always) */
 enum {
     AGAN_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity mode)             */
-    AGAN_PREC_BF16 = 1,  /* operands rounded to bf16 when staged, v_mfma_f32_32x32x16_bf16        */
+    AGAN_PREC_BF16 = 1,  /* (reserved) operands rounded to bf16, single MFMA pass: not built -- fails the 1e-3 parity bar */
     AGAN_PREC_BF16X3 = 2 /* bf16 hi/lo split, 3 MFMAs per product: ~fp32 accuracy at bf16 MFMA rate */
 };
 
@@ -77,9 +77,11 @@ enum {
     AGAN_PACK_UP_DGRAD = 4   /* its dgrad folded into one 4x4 stride-2 conv over dY                                         */
 };
 
-size_t agan_packed_weight_elems(int mode, int cout, int cin, int kh, int kw);
+/* Packed size in BYTES for a precision mode: AGAN_PREC_F32 -> fp32 [cls][K][Nld];  AGAN_PREC_BF16X3 -> bf16 hi and lo planes
+ * [cls][2][Nld][Kp] (Kp = K rounded up to 32, k fastest).  0 = mode/kernel-size/precision combination not supported. */
+size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
 /* w: OIHW [cout][cin][kh][kw] -> wk (see modes).  Replaces nothing in the reference: layout prep for the kernels below. */
-int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int kh, int kw, void* stream);
+int agan_pack_weight(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, void* stream);
 
 /* conv forward / dgrad: replaces F.conv2d fwd+dgrad under Layers.conv3x3 / conv4x4 s2 / Upsample+conv3x3 /
  * nn.Linear (1x1 on a 1x1 image) -- utilities/layers.py:50-53,64-65,122,139-150; generator_submodules.py:36,152;
@@ -90,8 +92,8 @@ int agan_pack_weight(const float* w, float* wk, int mode, int cout, int cin, int
 size_t agan_conv_ktable_elems(const agan_conv_geom* g);
 int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
 
-size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g);
-int agan_conv_gather(const float* in, const float* wk, const float* bias, float* out, const agan_conv_geom* g,
+size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
+int agan_conv_gather(const float* in, const void* wk, const float* bias, float* out, const agan_conv_geom* g,
                      const int32_t* ktable, int prec, void* ws, size_t ws_bytes, void* stream);
 
 /* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.

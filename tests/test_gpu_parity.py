@@ -22,7 +22,35 @@ ATT = importlib.import_module("attention-gan_amd.networks.attention")
 from oracle import attngan_oracle as O   # noqa: E402  (checker only)
 
 DEV = "cuda"
-TIGHT = 2e-4
+
+
+class _Tol:
+    """AGAN_PREC_F32 multiplies exactly in fp32: agreement is ~1e-6 and held to 2e-4.  AGAN_PREC_BF16X3 (3-term bf16 split,
+    ~2^-16 per product) is held to the north_star bar itself, 1e-3 relative."""
+    tight = 2e-4
+
+
+TOL = _Tol()
+
+
+# Tests that also run under AGAN_PREC_BF16X3.  The whole-network golden fixtures use batch 2-4, where train-mode BatchNorm
+# over a handful of samples amplifies any perturbation ~10^3x (the exact-fp32 mode itself lands at 1e-4..1e-3 there), so the
+# 2^-16 products of the split mode cannot meet 1e-3 on them; it is held to 1e-3 on the conv engine, the fused blocks and at
+# the metric batch size (test_bf16x3_vs_f32_at_metric_batch).  bench.py's default and the parity claim are the f32 mode.
+BF16X3_TESTS = ("test_conv_engine_vs_oracle", "test_conv_metric_shape_properties", "test_blocks_vs_golden",
+                "test_bf16x3_vs_f32_at_metric_batch")
+
+
+@pytest.fixture(params=["f32", "bf16x3"], autouse=True)
+def precision_mode(request):
+    if request.param == "bf16x3" and request.node.originalname not in BF16X3_TESTS:
+        pytest.skip("exact-fp32 mode only (see BF16X3_TESTS)")
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    HF.set_precision(L.PREC_F32 if request.param == "f32" else L.PREC_BF16X3)
+    TOL.tight = 2e-4 if request.param == "f32" else RTOL
+    yield request.param
+    HF.set_precision(L.PREC_F32)
+    TOL.tight = 2e-4
 
 
 def cu(a):
@@ -34,7 +62,8 @@ def load_state(module, state):
     return module.to(DEV).train()
 
 
-def check_param_grads(module, gold, tol=TIGHT):
+def check_param_grads(module, gold, tol=None):
+    tol = TOL.tight if tol is None else tol
     want = sub(gold, "gparam/")
     seen = 0
     for k, p in module.named_parameters():
@@ -45,7 +74,8 @@ def check_param_grads(module, gold, tol=TIGHT):
     assert seen == len(want)
 
 
-def check_running(module, gold, tol=TIGHT):
+def check_running(module, gold, tol=None):
+    tol = TOL.tight if tol is None else tol
     sd = module.state_dict()
     for k, v in sub(gold, "after/").items():
         assert_close(sd[k].double(), v.double(), tol, f"running {k}")
@@ -88,11 +118,11 @@ def test_conv_engine_vs_oracle(kind, B, Cin, H, Cout, k, bias):
     bd = b.to(DEV).requires_grad_(True) if bias else None
     y = HF.conv2d(xd, wd, bd, kind)
     (y * pr.to(DEV)).sum().backward()
-    assert_close(y, yr, TIGHT, "fwd")
-    assert_close(xd.grad, xr.grad, TIGHT, "dgrad")
-    assert_close(wd.grad, wr.grad, TIGHT, "wgrad")
+    assert_close(y, yr, TOL.tight, "fwd")
+    assert_close(xd.grad, xr.grad, TOL.tight, "dgrad")
+    assert_close(wd.grad, wr.grad, TOL.tight, "wgrad")
     if bias:
-        assert_close(bd.grad, br.grad, TIGHT, "bias grad")
+        assert_close(bd.grad, br.grad, TOL.tight, "bias grad")
 
 
 def test_conv_metric_shape_properties():
@@ -105,11 +135,44 @@ def test_conv_metric_shape_properties():
     x2 = torch.randn(B, Cin, H, H, generator=g).to(DEV)
     y1, y2 = HF.conv2d(x1, w, None, "same"), HF.conv2d(x2, w, None, "same")
     y12 = HF.conv2d(x1 + 2 * x2, w, None, "same")
-    assert_close(y12, y1 + 2 * y2, 1e-5, "linearity")
+    assert_close(y12, y1 + 2 * y2, 1e-5 if TOL.tight < 1e-3 else 1e-4, "linearity")
     ones = torch.ones(1, Cin, H, H, device=DEV)
     yo = HF.conv2d(ones, w, None, "same")
-    assert_close(yo[0, :, 5, 5], w.sum(dim=(1, 2, 3)), 1e-5, "interior = sum of taps")
-    assert_close(yo[0, :, 0, 0], w[:, :, 1:, 1:].sum(dim=(1, 2, 3)), 1e-5, "corner = 2x2 taps")
+    lin = 1e-5 if TOL.tight < 1e-3 else 1e-4
+    assert_close(yo[0, :, 5, 5], w.sum(dim=(1, 2, 3)), lin, "interior = sum of taps")
+    assert_close(yo[0, :, 0, 0], w[:, :, 1:, 1:].sum(dim=(1, 2, 3)), lin, "corner = 2x2 taps")
+
+
+def test_bf16x3_vs_f32_at_metric_batch(precision_mode):
+    """Disc256 at the metric batch (B=24, df=16 to keep it quick): forward, input gradient and weight gradients of the bf16x3
+    mode against the exact-fp32 mode of the same HIP path -- the well-conditioned regime the split mode is meant for."""
+    if precision_mode != "bf16x3":
+        pytest.skip("comparison is run once, from the bf16x3 instance")
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    torch.manual_seed(11)
+    D = DISC.Disc256(16).to(DEV).train()
+    x = (torch.rand(24, 3, 256, 256, device=DEV) * 2 - 1)
+    outs = {}
+    for mode in (L.PREC_F32, L.PREC_BF16X3):
+        HF.set_precision(mode)
+        D.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = D(xi)
+        (y * probe(y.shape, 0.2).to(DEV)).sum().backward()
+        outs[mode] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters()})
+    HF.set_precision(L.PREC_BF16X3)
+    ref, got = outs[L.PREC_F32], outs[L.PREC_BF16X3]
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+    print("bf16x3 vs f32 @B=24: y max-rel %.2e | dx L2 %.2e | worst weight-grad L2 %.2e" % (
+        float((got[0] - ref[0]).abs().max() / ref[0].abs().max()), l2(got[1], ref[1]), max(l2(got[2][k], ref[2][k]) for k in ref[2])))
+    assert_close(got[0], ref[0], RTOL, "D256(x) B=24")
+    # gradients: LeakyReLU kinks / BatchNorm mean-subtraction turn the 3e-5 per-layer noise of the split products into isolated
+    # large pointwise deviations (max-norm 1e-2..1e-1) while the gradient as a whole moves by ~2 % (measured 1.7 % on dx): bounded in L2.
+    # This is why bf16x3 is an opt-in throughput mode and NOT the parity mode.
+    assert l2(got[1], ref[1]) < 5e-2, "dx B=24"
+    for k in ref[2]:
+        assert l2(got[2][k], ref[2][k]) < 5e-2, f"grad {k} B=24"
 
 
 # ------------------------------------------------------------------------------------------------ blocks vs golden
@@ -129,9 +192,9 @@ def test_blocks_vs_golden(name):
     m = load_state(BLOCK_BUILDERS[name](), sub(g, "param/"))
     x = cu(g["x"]).requires_grad_(True)
     y = m(x)
-    assert_close(y, g["y"], TIGHT, "y")
+    assert_close(y, g["y"], TOL.tight, "y")
     (y * probe(y.shape, 0.5).to(DEV)).sum().backward()
-    assert_close(x.grad, g["g_x"], TIGHT, "g_x")
+    assert_close(x.grad, g["g_x"], TOL.tight, "g_x")
     check_param_grads(m, g)
     check_running(m, g)
 
@@ -150,12 +213,12 @@ def test_attention_vs_golden(name):
     images, words = cu(g["images"]).requires_grad_(True), cu(g["words"]).requires_grad_(True)
     m.apply_mask(cu(g["mask"]))
     ctx, attn = m(images, words)
-    assert_close(ctx, g["ctx"], TIGHT, "ctx")
-    assert_close(attn, g["attn"], TIGHT, "attn")
+    assert_close(ctx, g["ctx"], TOL.tight, "ctx")
+    assert_close(attn, g["attn"], TOL.tight, "attn")
     ((ctx * probe(ctx.shape, 0.1).to(DEV)).sum() + (attn * probe(attn.shape, 0.2).to(DEV)).sum()).backward()
-    assert_close(images.grad, g["g_images"], TIGHT, "g_images")
-    assert_close(words.grad, g["g_words"], TIGHT, "g_words")
-    assert_close(m.conv1.weight.grad, g["gparam/conv1.weight"], TIGHT, "g_conv1")
+    assert_close(images.grad, g["g_images"], TOL.tight, "g_images")
+    assert_close(words.grad, g["g_words"], TOL.tight, "g_words")
+    assert_close(m.conv1.weight.grad, g["gparam/conv1.weight"], TOL.tight, "g_conv1")
     mask = cu(g["mask"])
     for b in range(mask.shape[0]):
         dead = attn[b][mask[b] == 0]
@@ -172,15 +235,15 @@ def test_attention_all_masked_row_is_nan_and_metric_shape():
     ctx, attn = m(images, words)
     assert torch.isnan(attn[1]).all() and not torch.isnan(attn[0]).any()
     ref_ctx, ref_attn = O.attention_module(images[:1].cpu(), words[:1].cpu(), m.conv1.weight.detach().cpu(), mask[:1].cpu())
-    assert_close(ctx[:1], ref_ctx, TIGHT, "ctx @128x128")
-    assert_close(attn[:1], ref_attn, TIGHT, "attn @128x128")
+    assert_close(ctx[:1], ref_ctx, TOL.tight, "ctx @128x128")
+    assert_close(attn[:1], ref_attn, TOL.tight, "attn @128x128")
 
 
 def test_func_attention_vs_golden():
     g = load("a2_func_attention")
     w, a = ATT.func_attention(cu(g["query"]), cu(g["context"]), 4.0)
-    assert_close(w, g["wctx"], TIGHT, "wctx")
-    assert_close(a, g["attn"], TIGHT, "attn")
+    assert_close(w, g["wctx"], TOL.tight, "wctx")
+    assert_close(a, g["attn"], TOL.tight, "attn")
 
 
 # ------------------------------------------------------------------------------------------------ generator / discriminators
@@ -195,8 +258,8 @@ def test_generator_vs_golden():
         assert_close(fakes[i], g[f"fake{i}"], RTOL, f"fake{i}")
     for i in range(2):
         assert_close(attns[i], g[f"attn{i}"], RTOL, f"attn{i}")
-    assert_close(mu, g["mu"], TIGHT, "mu")
-    assert_close(logvar, g["logvar"], TIGHT, "logvar")
+    assert_close(mu, g["mu"], TOL.tight, "mu")
+    assert_close(logvar, g["logvar"], TOL.tight, "logvar")
     loss = sum((f * probe(f.shape, 0.6 + i).to(DEV)).sum() for i, f in enumerate(fakes))
     loss = loss + sum((a * probe(a.shape, 0.7 + i).to(DEV)).sum() for i, a in enumerate(attns))
     loss = loss + (mu * probe(mu.shape, 0.8).to(DEV)).sum() + (logvar * probe(logvar.shape, 0.9).to(DEV)).sum()
@@ -215,7 +278,7 @@ def test_discriminators_vs_golden(res):
     assert set(D.state_dict()) == set(sub(g, "param/"))
     x = cu(g["x"]).requires_grad_(True)
     y = D(x)
-    assert_close(y, g["y"], TIGHT, "y")
+    assert_close(y, g["y"], TOL.tight, "y")
     (y * probe(y.shape, 1.1).to(DEV)).sum().backward()
     assert_close(x.grad, g["g_x"], RTOL, "g_x")
     check_param_grads(D, g, RTOL)
@@ -233,10 +296,10 @@ def test_damsm_losses_vs_golden(tag):
     labels = torch.arange(4, device=DEV)
     wl, maps = WL(torch.device(DEV)).get_loss(feat, wemb, labels, T(g["lens"]), cids)
     sl = SL(torch.device(DEV)).get_loss(code, semb, labels, cids)
-    assert_close(wl, g[f"{tag}/wloss"], TIGHT, "wloss")
-    assert_close(sl, g[f"{tag}/sloss"], TIGHT, "sloss")
+    assert_close(wl, g[f"{tag}/wloss"], TOL.tight, "wloss")
+    assert_close(sl, g[f"{tag}/sloss"], TOL.tight, "sloss")
     for i, m in enumerate(maps):
-        assert_close(m, g[f"{tag}/map{i}"], TIGHT, f"map{i}")
+        assert_close(m, g[f"{tag}/map{i}"], TOL.tight, f"map{i}")
     (wl + sl).backward()
     assert_close(feat.grad, g[f"{tag}/g_feat"], RTOL, "g_feat")
     assert_close(wemb.grad, g[f"{tag}/g_wemb"], RTOL, "g_wemb")
@@ -248,7 +311,7 @@ def test_words_loss_single_word_and_metric_shape():
     WL = importlib.import_module("attention-gan_amd.losses.words_loss").WordsLoss
     g = load("a8_a9_damsm")
     wl, _ = WL(torch.device(DEV)).get_loss(cu(g["one/feat"]), cu(g["one/wemb"]), torch.arange(4, device=DEV), [1, 4, 10, 3], None)
-    assert_close(wl, g["one/wloss"], TIGHT, "wloss (1-word caption)")
+    assert_close(wl, g["one/wloss"], TOL.tight, "wloss (1-word caption)")
     # metric shape B=24, nef=256, T=10 against the oracle, fwd + bwd
     gen = torch.Generator().manual_seed(3)
     feat = torch.randn(24, 256, 17, 17, generator=gen)
@@ -260,7 +323,7 @@ def test_words_loss_single_word_and_metric_shape():
     fd, wd = feat.to(DEV).requires_grad_(True), wemb.to(DEV).requires_grad_(True)
     ld, _ = WL(torch.device(DEV)).get_loss(fd, wd, torch.arange(24, device=DEV), lens, None)
     ld.backward()
-    assert_close(ld, lr, TIGHT, "loss B=24")
+    assert_close(ld, lr, TOL.tight, "loss B=24")
     assert_close(fd.grad, fr.grad, RTOL, "dfeat B=24")
     assert_close(wd.grad, wr.grad, RTOL, "dwemb B=24")
 

@@ -39,11 +39,13 @@ def test_c_abi_argument_validation_without_gpu():
     """Entry points validate arguments before touching the device: bad geometry comes back as AGAN_EINVAL + message."""
     lib = L.load()
     g = L.ConvGeom()
-    assert lib.agan_conv_gather_ws_bytes(g) == 0
-    assert lib.agan_packed_weight_elems(L.PACK_UP_FWD, 8, 8, 4, 4) == 0          # folded upsample conv is 3x3 only
-    assert lib.agan_packed_weight_elems(L.PACK_FWD, 3, 32, 3, 3) == 32 * 9 * 32   # Nld = round_up(3, 32)
-    assert lib.agan_packed_weight_elems(L.PACK_UP_FWD, 64, 64, 3, 3) == 4 * 64 * 4 * 64
-    rc = lib.agan_conv_gather(None, None, None, None, g, 0, None, 0, None)
+    assert lib.agan_conv_gather_ws_bytes(g, L.PREC_F32) == 0
+    assert lib.agan_packed_weight_bytes(L.PACK_UP_FWD, 8, 8, 4, 4, L.PREC_F32) == 0          # folded upsample conv is 3x3 only
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_F32) == 32 * 9 * 32 * 4   # Nld = round_up(3, 32)
+    assert lib.agan_packed_weight_bytes(L.PACK_UP_FWD, 64, 64, 3, 3, L.PREC_F32) == 4 * 64 * 4 * 64 * 4
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16X3) == 2 * 32 * 288 * 2  # hi+lo planes [Nld][Kp]
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16) == 0               # single-pass bf16 is not built
+    rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, None, 0, None)
     assert rc == -1 and b"conv" in lib.agan_last_error()
 
 
