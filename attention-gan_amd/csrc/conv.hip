@@ -144,8 +144,10 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     // one K tile: `cur` = register set that is free (tile kt already sits in LDS buffer `buf`), `nxt` = set holding tile kt+1
-    auto step = [&](auto cur, auto nxt, int kt, int buf) {
-        if (kt + 2 < nkt) load_tile(cur, kt + 2);
+    // FULL = steady state (no conditionals, so the compiler's waitcnt bookkeeping stays exact across iterations)
+    auto step = [&](auto full, auto cur, auto nxt, int kt, int buf) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL || kt + 2 < nkt) load_tile(cur, kt + 2);
         // operand fragments are read one k-step ahead of the MFMAs that consume them (LDS latency off the critical path)
         float av[2][TM], bv[2][TN];
 #pragma unroll
@@ -166,8 +168,11 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
 #pragma unroll
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][a], av[c][b], acc[a][b], 0, 0, 0);
+            // keep the next step's LDS reads ahead of this step's MFMAs in the emitted order
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (kt + 1 < nkt) store_tile(nxt, buf ^ 1);
+        if (FULL || kt + 1 < nkt) store_tile(nxt, buf ^ 1);
         __syncthreads();
     };
 
@@ -175,9 +180,14 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
     if (nkt > 1) load_tile(S1{}, 1);
     if (nkt > 0) store_tile(S0{}, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(S0{}, S1{}, kt, 0);
-        if (kt + 1 < nkt) step(S1{}, S0{}, kt + 1, 1);
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+        step(std::true_type{}, S0{}, S1{}, kt, 0);
+        step(std::true_type{}, S1{}, S0{}, kt + 1, 1);
+    }
+    for (; kt < nkt; kt += 2) {
+        step(std::false_type{}, S0{}, S1{}, kt, 0);
+        if (kt + 1 < nkt) step(std::false_type{}, S1{}, S0{}, kt + 1, 1);
     }
 
     // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ---
@@ -347,8 +357,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    auto step = [&](auto cur, auto nxt, int pt, int buf) {
-        if (pt + 2 < npt) load_tile(cur, pt + 2);
+    auto step = [&](auto full, auto cur, auto nxt, int pt, int buf) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL || pt + 2 < npt) load_tile(cur, pt + 2);
         float av[2][TI], bv[2][TJ];
 #pragma unroll
         for (int t = 0; t < TI; ++t) av[0][t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][half];
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
                 for (int b = 0; b < TI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][a], av[c][b], acc[a][b], 0, 0, 0);
         }
-        if (pt + 1 < npt) store_tile(nxt, buf ^ 1);
+        if (FULL || pt + 1 < npt) store_tile(nxt, buf ^ 1);
         __syncthreads();
     };
 
@@ -377,9 +388,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     if (npt > 1) load_tile(S1{}, 1);
     if (npt > 0) store_tile(S0{}, 0);
     __syncthreads();
-    for (int pt = 0; pt < npt; pt += 2) {
-        step(S0{}, S1{}, pt, 0);
-        if (pt + 1 < npt) step(S1{}, S0{}, pt + 1, 1);
+    int pt = 0;
+    for (; pt + 3 < npt; pt += 2) {
+        step(std::true_type{}, S0{}, S1{}, pt, 0);
+        step(std::true_type{}, S1{}, S0{}, pt + 1, 1);
+    }
+    for (; pt < npt; pt += 2) {
+        step(std::false_type{}, S0{}, S1{}, pt, 0);
+        if (pt + 1 < npt) step(std::false_type{}, S1{}, S0{}, pt + 1, 1);
     }
 
     // D[cout][k index]: the lane owns one k column, so each register stores 32 consecutive floats of an OIHW row

@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3_kernel(const float*
     const int l31 = lane & 31, lh = lane >> 5;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    auto step = [&](auto cur, auto nxt, int kt, int buf) {
-        if (kt + 2 < nkt) load_tile(cur, kt + 2);
+    // FULL = steady state (no conditionals, so the compiler's waitcnt bookkeeping stays exact across iterations)
+    auto step = [&](auto full, auto cur, auto nxt, int kt, int buf) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL || kt + 2 < nkt) load_tile(cur, kt + 2);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int kc = ks * 16 + lh * 8;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3_kernel(const float*
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[a], ah[b], acc[a][b], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nkt) store_tile(nxt, buf ^ 1);
+        if (FULL || kt + 1 < nkt) store_tile(nxt, buf ^ 1);
         __syncthreads();
     };
 
@@ -196,9 +198,14 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3_kernel(const float*
     if (nkt > 1) load_tile(S1{}, 1);
     if (nkt > 0) store_tile(S0{}, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(S0{}, S1{}, kt, 0);
-        if (kt + 1 < nkt) step(S1{}, S0{}, kt + 1, 1);
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+        step(std::true_type{}, S0{}, S1{}, kt, 0);
+        step(std::true_type{}, S1{}, S0{}, kt + 1, 1);
+    }
+    for (; kt < nkt; kt += 2) {
+        step(std::false_type{}, S0{}, S1{}, kt, 0);
+        if (kt + 1 < nkt) step(std::false_type{}, S1{}, S0{}, kt + 1, 1);
     }
 
     // ---- epilogue: D[cout][pixel] (same accumulator layout as the f32 kernel) ----
@@ -331,8 +338,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const float* 
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    auto step = [&](auto cur, auto nxt, int pt, int buf) {
-        if (pt + 2 < npt) load_tile(cur, pt + 2);
+    auto step = [&](auto full, auto cur, auto nxt, int pt, int buf) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL || pt + 2 < npt) load_tile(cur, pt + 2);
 #pragma unroll
         for (int ks = 0; ks < BP / 16; ++ks) {
             const int pc = ks * 16 + lh * 8;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const float* 
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[a], xh[b], acc[a][b], 0, 0, 0);
                 }
         }
-        if (pt + 1 < npt) store_tile(nxt, buf ^ 1);
+        if (FULL || pt + 1 < npt) store_tile(nxt, buf ^ 1);
         __syncthreads();
     };
 
@@ -364,9 +372,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const float* 
     if (npt > 1) load_tile(S1{}, 1);
     if (npt > 0) store_tile(S0{}, 0);
     __syncthreads();
-    for (int pt = 0; pt < npt; pt += 2) {
-        step(S0{}, S1{}, pt, 0);
-        if (pt + 1 < npt) step(S1{}, S0{}, pt + 1, 1);
+    int pt = 0;
+    for (; pt + 3 < npt; pt += 2) {
+        step(std::true_type{}, S0{}, S1{}, pt, 0);
+        step(std::true_type{}, S1{}, S0{}, pt + 1, 1);
+    }
+    for (; pt < npt; pt += 2) {
+        step(std::false_type{}, S0{}, S1{}, pt, 0);
+        if (pt + 1 < npt) step(std::false_type{}, S1{}, S0{}, pt + 1, 1);
     }
 
     // D[cout][k index]

@@ -1,0 +1,137 @@
+"""Data-parallel path on real kernels: two ranks (gloo rendezvous, both on the one GPU of the test box -- RCCL needs one
+device per rank, the driver exercises that at N=2..8) run GanTrainStep on different shards; the result must equal the
+single-process computation  mean over shards of (per-shard gradients with per-shard BatchNorm statistics) -> one Adam step."""
+import importlib
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEN = importlib.import_module("attention-gan_amd.networks.generator")
+DISC = importlib.import_module("attention-gan_amd.networks.discriminators")
+ENC = importlib.import_module("attention-gan_amd.networks.cnn_encoder")
+TR = importlib.import_module("attention-gan_amd.trainers.trainer")
+OPT = importlib.import_module("attention-gan_amd.optim")
+
+DIMS = dict(gf=4, df=4, emb=16, z=8, cond=8, B=4, T=5)
+
+
+def _nets(dev):
+    torch.manual_seed(123)
+    d = DIMS
+    G = GEN.Generator(d["gf"], d["emb"], d["z"], d["cond"]).to(dev)
+    Ds = [DISC.Disc64(d["df"]).to(dev), DISC.Disc128(d["df"]).to(dev), DISC.Disc256(d["df"]).to(dev)]
+    enc = ENC.StandInImageEncoder(d["emb"]).to(dev)
+    enc.freeze_all_weights()
+    return G, Ds, enc
+
+
+def _shard(rank, dev):
+    d = DIMS
+    g = torch.Generator().manual_seed(1000 + rank)
+    words, sent = torch.randn(d["B"], d["emb"], d["T"], generator=g).to(dev), torch.randn(d["B"], d["emb"], generator=g).to(dev)
+    noise, eps = torch.randn(d["B"], d["z"], generator=g).to(dev), torch.randn(d["B"], d["cond"], generator=g).to(dev)
+    reals = [(torch.rand(d["B"], 3, r, r, generator=g) * 2 - 1).to(dev) for r in (64, 128, 256)]
+    return words, sent, [5, 3, 2, 4], reals, noise, eps
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        G, Ds, enc = _nets(dev)
+        step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=64 << 10)          # small buckets -> several exchanges per optimiser
+        words, sent, lens, reals, noise, eps = _shard(rank, dev)
+        out = step.step(words, sent, lens, None, reals, noise, eps)
+        torch.cuda.synchronize()
+        # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
+        q.put((rank, {k: v.detach().cpu().numpy() for k, v in G.state_dict().items()},
+               [{k: v.detach().cpu().numpy() for k, v in d.state_dict().items()} for d in Ds], len(step.g_buckets.bounds)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_mean_of_shard_gradients():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = [(r, {k: torch.from_numpy(v) for k, v in g.items()}, [{k: torch.from_numpy(v) for k, v in d.items()} for d in ds], nb)
+           for r, g, ds, nb in got]
+    assert got[0][3] > 1                                              # more than one gradient bucket was exchanged
+    for k, v in got[0][1].items():                                    # replicas end the step with identical weights
+        if k.endswith((".weight", ".bias")):
+            assert torch.equal(v, got[1][1][k]), k
+
+    # single-process reference: per-shard gradients (per-shard BN statistics), averaged, one Adam step each
+    dev = torch.device("cuda", 0)
+    G, Ds, enc = _nets(dev)
+    g_opt = OPT.FlatAdam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opts = [OPT.FlatAdam(d.parameters(), lr=2e-4, betas=(0.5, 0.999)) for d in Ds]
+    ref = TR.GanTrainStep.__new__(TR.GanTrainStep)                     # borrow the loss helpers without re-homing twice
+    TR.ModelTrainer.__init__(ref)
+    WL = importlib.import_module("attention-gan_amd.losses.words_loss").WordsLoss(dev, 4.0, 5.0, 10.0, 5.0)
+    SL = importlib.import_module("attention-gan_amd.losses.sentence_loss").SentenceLoss(dev, 10.0, 5.0)
+    DL = importlib.import_module("attention-gan_amd.losses.disc_loss").NonSaturatingDiscLoss()
+    GL = importlib.import_module("attention-gan_amd.losses.gen_loss").NonSaturatingGenLoss()
+    KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
+    shards = [_shard(r, dev) for r in range(2)]
+    bn_state = [{k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k} for m in [G] + Ds]
+    fakes_all = []
+    for words, sent, lens, reals, noise, eps in shards:               # generator forward per shard (its BN stats are per shard)
+        G.load_state_dict(bn_state[0], strict=False)
+        fakes_all.append(G(noise, sent, words, ref._make_mask(lens), eps))
+    for i, (d, opt) in enumerate(zip(Ds, d_opts)):
+        acc = torch.zeros_like(opt.grad)
+        for s, (words, sent, lens, reals, noise, eps) in enumerate(shards):
+            d.load_state_dict(bn_state[1 + i], strict=False)
+            opt.zero_grad()
+            DL.get_loss(d, fakes_all[s][0][i].detach(), reals[i]).backward()
+            acc += opt.grad
+        opt.grad.copy_(acc)
+        opt.step(0.5)
+    g_acc = torch.zeros_like(g_opt.grad)
+    for d in Ds:
+        d.requires_grad_(False)
+    d_bn_after = [{k: v.clone() for k, v in d.state_dict().items() if "running" in k or "num_batches" in k} for d in Ds]
+    for s, (words, sent, lens, reals, noise, eps) in enumerate(shards):
+        fakes, _, mu, logvar = fakes_all[s]
+        g_opt.zero_grad()
+        total = KL(mu, logvar)
+        for i, d in enumerate(Ds):
+            d.load_state_dict(d_bn_after[i], strict=False)
+            total = total + GL.get_loss(d, fakes[i])
+        regions, code = enc(fakes[2])
+        labels = torch.arange(DIMS["B"], device=dev)
+        total = total + WL.get_loss(regions, words, labels, lens, None)[0] + SL.get_loss(code, sent, labels, None)
+        total.backward()
+        g_acc += g_opt.grad
+    g_opt.grad.copy_(g_acc)
+    g_opt.step(0.5)
+    torch.cuda.synchronize()
+
+    def close(a, b, what):
+        scale = float(b.abs().max().clamp(min=1e-30))
+        diff = (a.to(b.device) - b).abs()
+        bad = int((diff > 1e-3 * scale).sum())
+        assert float(diff.max()) <= 2.05 * 2e-4 and bad <= max(2, b.numel() // 1000), f"{what}: {bad} of {b.numel()} off, max {float(diff.max()):.2e}"
+
+    for k, v in G.state_dict().items():
+        if k.endswith((".weight", ".bias")):
+            close(got[0][1][k], v.cpu(), f"G {k}")
+    for i, d in enumerate(Ds):
+        for k, v in d.state_dict().items():
+            if k.endswith((".weight", ".bias")):
+                close(got[0][2][i][k], v.cpu(), f"D{i} {k}")
