@@ -54,6 +54,33 @@ def _ws(nbytes: int, like: Tensor) -> Tuple[Optional[Tensor], Optional[c_void_p]
 
 
 # --------------------------------------------------------------------------------------------------------------
+# gradient destinations: optim.FlatAdam tags every parameter with `_agan_grad_dst = (flat_grad, offset, numel)`.  Backward
+# kernels then write weight gradients straight into the flat buffer and hand autograd a fresh view of it, so AccumulateGrad
+# adopts the view (p.grad is None at that point) instead of launching one `grad += new` kernel per parameter.
+# --------------------------------------------------------------------------------------------------------------
+def grad_dst(param):
+    return getattr(param, "_agan_grad_dst", None)
+
+
+def _grad_out(dst, shape, like: Tensor) -> Tensor:
+    """Where a backward kernel should write a parameter gradient.  The FIRST contribution of a backward pass goes straight
+    into the flat buffer (autograd then adopts that view as p.grad); a parameter used more than once per backward (a
+    discriminator sees the real and the fake batch) gets its later contributions in scratch tensors that autograd adds."""
+    if dst is None or dst.written:
+        return torch.empty(shape, dtype=torch.float32, device=like.device)
+    dst.written = True
+    return dst.flat[dst.offset:dst.offset + dst.numel].view(shape)
+
+
+class GradDst:
+    """Slice of a FlatAdam gradient buffer that belongs to one parameter (+ 'already written in this backward' flag)."""
+    __slots__ = ("flat", "offset", "numel", "written")
+
+    def __init__(self, flat: Tensor, offset: int, numel: int):
+        self.flat, self.offset, self.numel, self.written = flat, offset, numel, False
+
+
+# --------------------------------------------------------------------------------------------------------------
 # convolution geometry (see include/agan.h: agan_conv_geom)
 # --------------------------------------------------------------------------------------------------------------
 def _geom(B, Cin, IH, IW, Cout, OH, OW, R, S, OS, SY, DY, OY) -> L.ConvGeom:
@@ -164,7 +191,7 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
 
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict]):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst):
         x = _dev(x, "conv input")
         w = _dev(weight.detach(), "conv weight")
         B, Cin, H, W = x.shape
@@ -176,7 +203,7 @@ class _ConvFn(Function):
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
         _gather(x, packed_weight(w, pf, cache), b, gf, out, kind, "fwd")
         ctx.save_for_backward(x, w)
-        ctx.kind, ctx.has_bias, ctx.cache = kind, bias is not None, cache
+        ctx.kind, ctx.has_bias, ctx.cache, ctx.wdst, ctx.bdst = kind, bias is not None, cache, wdst, bdst
         return out
 
     @staticmethod
@@ -192,7 +219,7 @@ class _ConvFn(Function):
             dx = torch.empty_like(x)
             _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw = _grad_out(ctx.wdst, w.shape, x)
             lib = L.load()
             nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
             ws, wsp = _ws(nbytes, x)
@@ -204,20 +231,22 @@ class _ConvFn(Function):
             if obs is not None:
                 obs.end()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            db = _grad_out(ctx.bdst, (Cout,), x)
             L.call("agan_bias_grad", _p(dy), _p(db), B, Cout, dy.shape[2] * dy.shape[3], _stream())
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None) -> Tensor:
-    """conv forward with autograd (dgrad + wgrad kernels).  kind: 'same' | 'down' | 'up' (conv_geoms)."""
-    return _ConvFn.apply(x, weight, bias, kind, cache)
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None,
+           wdst=None, bdst=None) -> Tensor:
+    """conv forward with autograd (dgrad + wgrad kernels).  kind: 'same' | 'down' | 'up' (conv_geoms).
+    wdst / bdst: optional flat-gradient destinations of weight / bias (grad_dst(param))."""
+    return _ConvFn.apply(x, weight, bias, kind, cache, wdst, bdst)
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Optional[dict] = None) -> Tensor:
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Optional[dict] = None, wdst=None, bdst=None) -> Tensor:
     """nn.Linear as a 1x1 conv on a 1x1 image (generator_submodules.py:36,152)."""
     B, Cin = x.shape
-    y = _ConvFn.apply(x.reshape(B, Cin, 1, 1), weight.view(weight.shape[0], Cin, 1, 1), bias, "same", cache)
+    y = _ConvFn.apply(x.reshape(B, Cin, 1, 1), weight.view(weight.shape[0], Cin, 1, 1), bias, "same", cache, wdst, bdst)
     return y.view(B, weight.shape[0])
 
 
@@ -226,7 +255,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Opti
 # --------------------------------------------------------------------------------------------------------------
 class _BnActFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum, gdst, bdst):
         x = _dev(x, "bn input")
         shape = x.shape
         B, C = shape[0], shape[1]
@@ -248,7 +277,7 @@ class _BnActFn(Function):
         res = _dev(residual, "bn residual") if residual is not None else None
         L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
         ctx.save_for_backward(x, g, b, mean, invstd)
-        ctx.act, ctx.training, ctx.has_res = act, training, residual is not None
+        ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst = act, training, residual is not None, gdst, bdst
         return out
 
     @staticmethod
@@ -261,18 +290,19 @@ class _BnActFn(Function):
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dx = torch.empty_like(x)
-        dg, db = torch.empty_like(g), torch.empty_like(b)
+        dg, db = _grad_out(ctx.gdst, g.shape, x), _grad_out(ctx.bdst, b.shape, x)
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(B, C, HW)
         ws, wsp = _ws(nbytes, x)
         L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dg), _p(db), B, C, HW,
                ctx.act, wsp, nbytes, _stream())
         dres = dout if ctx.has_res else None
-        return dx, dg, db, dres, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, nbt, training: bool, act: int, residual=None,
            eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
-    return _BnActFn.apply(x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum)
+    return _BnActFn.apply(x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum,
+                          grad_dst(gamma), grad_dst(beta))
 
 
 class _ActFn(Function):
@@ -332,7 +362,7 @@ def glu(x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------------------------
 class _AttentionFn(Function):
     @staticmethod
-    def forward(ctx, images, words, weight, mask, scale):
+    def forward(ctx, images, words, weight, mask, scale, wdst):
         images, words = _dev(images, "attention images"), _dev(words, "attention words")
         w = _dev(weight.detach(), "attention conv1 weight")
         B, C, H, W = images.shape
@@ -346,7 +376,7 @@ class _AttentionFn(Function):
         L.call("agan_attn_fwd", _p(images), _p(words), _p(w), _p(m), float(scale), _p(proj), _p(ctxt), _p(attn),
                B, C, E, T, H * W, _stream())
         ctx.save_for_backward(images, words, w, proj, attn)
-        ctx.scale = float(scale)
+        ctx.scale, ctx.wdst = float(scale), wdst
         return ctxt, attn
 
     @staticmethod
@@ -357,18 +387,18 @@ class _AttentionFn(Function):
         _, E, T = words.shape
         dctx = _dev(dctx, "attention dctx") if dctx is not None else None
         dattn = _dev(dattn, "attention dattn") if dattn is not None else None
-        dimages, dwords, dw = torch.empty_like(images), torch.empty_like(words), torch.empty_like(w)
+        dimages, dwords, dw = torch.empty_like(images), torch.empty_like(words), _grad_out(ctx.wdst, w.shape, images)
         nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T)
         ws, wsp = _ws(nbytes, images)
         L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
                _p(dimages), _p(dwords), _p(dw), B, C, E, T, H * W, wsp, nbytes, _stream())
-        return dimages, dwords, dw.view_as(w), None, None
+        return dimages, dwords, dw, None, None, None
 
 
 def attention(images: Tensor, words: Tensor, conv1_weight: Tensor, mask: Tensor, scaled: bool = True):
     C = images.shape[1]
     scale = 1.0 / math.sqrt(C) if scaled else 1.0
-    return _AttentionFn.apply(images, words, conv1_weight, mask, scale)
+    return _AttentionFn.apply(images, words, conv1_weight, mask, scale, grad_dst(conv1_weight))
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ class GradBuckets:
             self.param_bucket.append(b)
         self.bounds.append((start, opt.numel))
         self.counts = [self.param_bucket.count(i) for i in range(len(self.bounds))]
+        self.members = [[i for i, b in enumerate(self.param_bucket) if b == k] for k in range(len(self.bounds))]
         self._pending = list(self.counts)
         self._handles: List = []
         self._armed = False
@@ -76,7 +77,7 @@ class GradBuckets:
 
     def _launch(self, b: int) -> None:
         s, e = self.bounds[b]
-        self.opt._rebind()
+        self.opt._rebind(self.members[b])      # only this bucket's parameters: the others may still be mid-backward
         chunk = self.opt.grad[s:e]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())

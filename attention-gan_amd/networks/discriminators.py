@@ -21,7 +21,8 @@ class _LogitHead(nn.Module):
         b, c, h, w = x.shape
         if (h, w) != (4, 4):
             raise ValueError(f"discriminator head expects a 4x4 code, got {h}x{w}")
-        logit = HF.linear(x.reshape(b, c * 16), conv.weight.view(1, c * 16), conv.bias, self._packed)
+        logit = HF.linear(x.reshape(b, c * 16), conv.weight.view(1, c * 16), conv.bias, self._packed,
+                          HF.grad_dst(conv.weight), HF.grad_dst(conv.bias))
         return HF.activation(logit, L.ACT_SIGMOID)
 
 

@@ -38,20 +38,35 @@ class FlatAdam:
                 self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._agan_grad_dst = HF.GradDst(self.grad, o, p.numel())   # backward kernels write here directly
         self.step_count = 0
 
     # -- torch.optim-like surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
+        """Zero the flat gradient buffer and drop the per-parameter .grad references: the backward kernels write each
+        gradient straight into its slice of the flat buffer and autograd adopts that view (no accumulate kernels)."""
         self.grad.zero_()
-        self._rebind()
+        for p in self.params:
+            p.grad = None
+            p._agan_grad_dst.written = False
 
-    def _rebind(self) -> None:
-        for p, o in zip(self.params, self.offsets):
+    def _rebind(self, indices=None) -> int:
+        """Make p.grad the view into the flat buffer (for all parameters, or the given indices); gradients that landed
+        elsewhere (a kernel without a flat destination, or autograd cloning instead of adopting) are copied in.
+        Returns how many copies were needed."""
+        copies = 0
+        base = self.grad.data_ptr()
+        it = zip(self.params, self.offsets) if indices is None else ((self.params[i], self.offsets[i]) for i in indices)
+        for p, o in it:
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * o:
+                continue
             view = self.grad[o:o + p.numel()].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
+            if g is not None:
+                view.copy_(g)
+                copies += 1
+            p.grad = view
+        return copies
 
     def step(self, grad_scale: float = 1.0) -> None:
         self._rebind()

@@ -36,7 +36,8 @@ class HipConv2d(nn.Conv2d):
         self._packed = {}        # packed-weight cache (layout copies for the kernels; not part of state_dict)
 
     def forward(self, x: Tensor) -> Tensor:
-        return HF.conv2d(x, self.weight, self.bias, self.kind, self._packed)
+        return HF.conv2d(x, self.weight, self.bias, self.kind, self._packed, HF.grad_dst(self.weight),
+                         HF.grad_dst(self.bias) if self.bias is not None else None)
 
 
 class HipLinear(nn.Linear):
@@ -45,7 +46,8 @@ class HipLinear(nn.Linear):
         self._packed = {}
 
     def forward(self, x: Tensor) -> Tensor:
-        return HF.linear(x, self.weight, self.bias, self._packed)
+        return HF.linear(x, self.weight, self.bias, self._packed, HF.grad_dst(self.weight),
+                         HF.grad_dst(self.bias) if self.bias is not None else None)
 
 
 class _BNState:

@@ -99,6 +99,7 @@ def test_two_rank_step_equals_mean_of_shard_gradients():
             d.load_state_dict(bn_state[1 + i], strict=False)
             opt.zero_grad()
             DL.get_loss(d, fakes_all[s][0][i].detach(), reals[i]).backward()
+            opt._rebind()
             acc += opt.grad
         opt.grad.copy_(acc)
         opt.step(0.5)
@@ -117,6 +118,7 @@ def test_two_rank_step_equals_mean_of_shard_gradients():
         labels = torch.arange(DIMS["B"], device=dev)
         total = total + WL.get_loss(regions, words, labels, lens, None)[0] + SL.get_loss(code, sent, labels, None)
         total.backward()
+        g_opt._rebind()
         g_acc += g_opt.grad
     g_opt.grad.copy_(g_acc)
     g_opt.step(0.5)

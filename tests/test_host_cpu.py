@@ -124,6 +124,10 @@ def test_flat_adam_rehomes_parameters_and_speaks_adam_state_dict():
         assert p.data_ptr() == base + 4 * o and o % 4 == 0 and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * o
     lin(torch.randn(2, 5)).sum().backward()
     assert float(opt.grad.abs().sum()) > 0                      # autograd accumulated straight into the flat buffer
+    opt.zero_grad()
+    assert all(p.grad is None for p in opt.params) and float(opt.grad.abs().sum()) == 0
+    lin(torch.randn(2, 5)).sum().backward()
+    assert opt._rebind() == len(opt.params) and float(opt.grad.abs().sum()) > 0   # stock torch grads are copied in
     sd = opt.state_dict()
     ref = torch.optim.Adam(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)).parameters(), lr=2e-4, betas=(0.5, 0.999))
     assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "params"} and sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
@@ -187,6 +191,7 @@ def test_data_parallel_gradient_exchange_gloo_world2():
     for r in range(2):
         opt.zero_grad()
         net(torch.randn(4, 16, generator=torch.Generator().manual_seed(r))).pow(2).sum().backward()
+        opt._rebind()                      # what step() does: gradients autograd kept outside the flat buffer are copied in
         total += opt.grad
     assert torch.allclose(g0, total, rtol=1e-5, atol=1e-6)
 
