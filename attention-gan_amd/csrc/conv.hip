@@ -562,7 +562,9 @@ int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int
 
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (check_geom(g)) return 0;
-    return plan_gather(make_geom(g), prec).ws_bytes;
+    const Geom gg = make_geom(g);
+    if (prec == AGAN_PREC_F32 && small_n_gather_supported(gg)) return 0;
+    return plan_gather(gg, prec).ws_bytes;
 }
 
 size_t agan_conv_ktable_elems(const agan_conv_geom* g) {
@@ -588,12 +590,16 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_gather: precision mode %d not built in this version", prec);
     const Geom g = make_geom(gg);
+    hipStream_t st = as_stream(stream);
+    if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {
+        launch_gather_small_n(in, wk, bias, out, g, st);
+        return check_launch("conv_gather/small_n");
+    }
     const GatherPlan p = plan_gather(g, prec);
     if (p.ws_bytes > ws_bytes || (p.ws_bytes && !ws)) {
         set_error("conv_gather: workspace %zu < %zu", ws_bytes, p.ws_bytes);
         return AGAN_EWORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
     if (prec == AGAN_PREC_BF16X3) launch_gather_bf16x3(in, wkv, bias, dst, ktab, g, p, st);
     else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
@@ -612,7 +618,10 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
 
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (check_geom(g)) return 0;
-    return plan_wgrad(make_geom(g), g->OS == 2).ws_bytes;
+    const Geom gg = make_geom(g);
+    // the larger of the two candidate paths (the small-N path is fp32-only; the caller does not pass the precision here)
+    const size_t a = plan_wgrad(gg, g->OS == 2).ws_bytes;
+    return small_n_wgrad_supported(gg) ? std::max(a, plan_wgrad_small_n(gg).ws_bytes) : a;
 }
 
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
@@ -625,12 +634,25 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     const bool up = pack_mode == AGAN_PACK_UP_FWD;
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
+    hipStream_t st = as_stream(stream);
+    if (prec == AGAN_PREC_F32 && !up && small_n_wgrad_supported(g)) {
+        const SmallWgradPlan sp = plan_wgrad_small_n(g);
+        if (sp.ws_bytes > ws_bytes || !ws) {
+            set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, sp.ws_bytes);
+            return AGAN_EWORKSPACE;
+        }
+        float* part = static_cast<float*>(ws);
+        launch_wgrad_small_n(x, dy, part, g, sp, st);
+        const size_t n = (size_t)g.Cout * g.K;
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, part, sp.nchunk,
+                           n, sp.slab, (const float*)nullptr, 1, 1, dw);
+        return check_launch("conv_wgrad/small_n");
+    }
     const WgradPlan p = plan_wgrad(g, up);
     if (p.ws_bytes > ws_bytes || (p.ws_bytes && !ws)) {
         set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, p.ws_bytes);
         return AGAN_EWORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
     float* wsf = static_cast<float*>(ws);
     // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine

@@ -196,6 +196,17 @@ inline WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     return p;
 }
 
+// <= 4 output channels on the vector ALU (conv_small.hip); fp32 only
+struct SmallWgradPlan {
+    int pchunk, nchunk;
+    size_t slab, ws_bytes;
+};
+bool small_n_gather_supported(const Geom& g);
+void launch_gather_small_n(const float* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st);
+bool small_n_wgrad_supported(const Geom& g);
+SmallWgradPlan plan_wgrad_small_n(const Geom& g);
+void launch_wgrad_small_n(const float* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st);
+
 // AGAN_PREC_BF16X3 kernels (conv_bf16.hip)
 int pack_weight_bf16x3(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, hipStream_t st);
 void launch_gather_bf16x3(const float* in, const void* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,

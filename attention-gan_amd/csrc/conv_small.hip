@@ -1,0 +1,177 @@
+// Convolutions with at most 4 output channels (the generator's RGB heads, the discriminators' gradient w.r.t. the image,
+// the 1-logit discriminator head).  On the MFMA tiles 29 of 32 accumulator rows would be padding, so these HBM-bound layers
+// run on the vector ALU instead: lanes along pixels (coalesced NCHW), the <= 4 output channels in registers, weights read
+// with scalar loads (they are wave-uniform), and the per-tap image offsets -- with the padding test already folded in as an
+// out-of-range buffer offset -- computed ONCE per pixel; the channel stride goes into the buffer instruction's scalar
+// offset, so the inner loop is one buffer_load + Cout FMAs per (channel, tap).
+#include "conv_common.h"
+
+using namespace agan;
+using namespace agan::conv;
+
+namespace {
+
+__device__ __forceinline__ float buf_load_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// forward / dgrad, Cout <= 4.  RS = taps per class (1, 4, 9, 16), S = tap columns.
+template <int RS, int S>
+__global__ __launch_bounds__(256) void conv_small_n_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+                                                           const float* __restrict__ bias, float* __restrict__ out, const Geom g) {
+    const int cls = blockIdx.y;
+    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = m < g.Mtot;
+    const int mm = valid ? m : 0;
+    const int b = g.dHWs.div(mm), rem = mm - b * g.HWs;
+    const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
+    const int iy0 = yq * g.SY + (py ? g.OY1 : g.OY0), ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
+    const int ihw = g.IH * g.IW;
+    const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
+    unsigned off[RS];
+#pragma unroll
+    for (int t = 0; t < RS; ++t) {
+        const int dy = (t / S) * g.DY, dx = (t % S) * g.DY;
+        const bool ok = valid & ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
+        off[t] = ok ? (unsigned)(pix0 + dy * g.IW + dx) * 4u : kOOB;
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const float* wc = wk + (size_t)cls * g.K * g.Nld;      // packed fp32 weights [K][Nld]: row k starts with the <= 4 live columns
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < g.Cin; ++c) {
+        const unsigned soff = (unsigned)(c * ihw) * 4u;
+        const float* wr = wc + (size_t)c * RS * g.Nld;
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+            const float v = buf_load_s(rin, off[t], soff);
+            const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)t * g.Nld);      // wave-uniform -> s_load_dwordx4
+            a0 += v * w.x; a1 += v * w.y; a2 += v * w.z; a3 += v * w.w;
+        }
+    }
+    if (!valid) return;
+    const size_t ohw = (size_t)g.OH * g.OW;
+    float* o = out + (size_t)b * g.Cout * ohw + (size_t)(yq * g.OS + py) * g.OW + (xq * g.OS + px);
+    const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        if (n < g.Cout) o[(size_t)n * ohw] = acc[n] + (bias ? bias[n] : 0.f);
+}
+
+// one output row per workgroup: out[m][n] = sum_k in[m][k] * w[k][n], n < 4   (discriminator logit: K = 8192, M = batch)
+__global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int K, int Nld, int Cout) {
+    __shared__ float red[4][4];
+    const int m = blockIdx.x;
+    const float* x = in + (size_t)m * K;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = x[k];
+        const float4 w = *reinterpret_cast<const float4*>(wk + (size_t)k * Nld);
+        a[0] += v * w.x; a[1] += v * w.y; a[2] += v * w.z; a[3] += v * w.w;
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) a[n] = wave_sum(a[n]);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int n = 0; n < 4; ++n) red[n][w] = a[n];
+    __syncthreads();
+    if (threadIdx.x < Cout) {
+        const int n = threadIdx.x;
+        out[(size_t)m * Cout + n] = red[n][0] + red[n][1] + red[n][2] + red[n][3] + (bias ? bias[n] : 0.f);
+    }
+}
+
+// weight gradient of a direct (OS = 1) conv with Cout <= 4: one workgroup = one input channel x one chunk of pixels.
+// Each lane walks its pixels with RS*Cout running sums in registers; they meet once per workgroup (wave shuffle + LDS).
+template <int RS, int S>
+__global__ __launch_bounds__(256) void wgrad_small_n_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                            const Geom g, const int pchunk, const size_t slab) {
+    __shared__ float red[4][RS * 4];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int pbeg = chunk * pchunk, pend = min(g.Mtot, pbeg + pchunk);
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const unsigned soff = (unsigned)(c * ihw) * 4u;
+    float acc[RS][4];
+#pragma unroll
+    for (int t = 0; t < RS; ++t)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[t][n] = 0.f;
+    for (int p = pbeg + threadIdx.x; p < pend; p += 256) {
+        const int b = g.dHWs.div(p), rem = p - b * g.HWs;
+        const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
+        const int iy0 = yq * g.SY + g.OY0, ix0 = xq * g.SY + g.OY0;
+        const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
+        const float* dp = dy + (size_t)b * g.Cout * ohw + (size_t)yq * g.OW + xq;
+        float d[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) d[n] = n < g.Cout ? dp[(size_t)n * ohw] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+            const int ddy = (t / S) * g.DY, ddx = (t % S) * g.DY;
+            const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
+            const float v = buf_load_s(rx, ok ? (unsigned)(pix0 + ddy * g.IW + ddx) * 4u : kOOB, soff);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[t][n] += v * d[n];
+        }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < RS; ++t)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float s = wave_sum(acc[t][n]);
+            if (lane == 0) red[w][t * 4 + n] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < RS * 4) {
+        const int t = threadIdx.x >> 2, n = threadIdx.x & 3;
+        if (n < g.Cout)
+            part[(size_t)chunk * slab + (size_t)n * g.K + c * RS + t] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+}  // namespace
+
+namespace agan {
+namespace conv {
+
+bool small_n_gather_supported(const Geom& g) {
+    if (g.Cout > 4 || g.R != g.S) return false;
+    return g.RS == 1 || g.RS == 4 || g.RS == 9 || g.RS == 16;
+}
+
+void launch_gather_small_n(const float* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st) {
+    if (g.RS == 1 && g.IH == 1 && g.IW == 1 && g.OS == 1 && g.SY == 1 && g.OY0 == 0) {       // a linear layer: one row per workgroup
+        hipLaunchKernelGGL(linear_small_n_kernel, dim3(g.Mtot), dim3(256), 0, st, in, wk, bias, out, g.K, g.Nld, g.Cout);
+        return;
+    }
+    dim3 grid(cdiv(g.Mtot, 256), g.OS * g.OS);
+    switch (g.RS) {
+        case 1: hipLaunchKernelGGL((conv_small_n_kernel<1, 1>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
+        case 4: hipLaunchKernelGGL((conv_small_n_kernel<4, 2>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
+        case 9: hipLaunchKernelGGL((conv_small_n_kernel<9, 3>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
+        default: hipLaunchKernelGGL((conv_small_n_kernel<16, 4>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
+    }
+}
+
+bool small_n_wgrad_supported(const Geom& g) { return g.Cout <= 4 && g.OS == 1 && g.R == 3 && g.S == 3 && g.Mtot >= 4096; }
+
+SmallWgradPlan plan_wgrad_small_n(const Geom& g) {
+    SmallWgradPlan p;
+    const int want = std::max(1, 8192 / std::max(1, g.Cin));                 // ~8k workgroups in total
+    p.pchunk = std::max(2048, cdiv(cdiv(g.Mtot, want), 256) * 256);
+    p.nchunk = cdiv(g.Mtot, p.pchunk);
+    p.slab = ((size_t)g.Cout * g.K + 3) / 4 * 4;
+    p.ws_bytes = p.slab * p.nchunk * sizeof(float);
+    return p;
+}
+
+void launch_wgrad_small_n(const float* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st) {
+    hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+}
+
+}  // namespace conv
+}  // namespace agan
