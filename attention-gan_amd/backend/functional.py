@@ -62,14 +62,21 @@ def grad_dst(param):
     return getattr(param, "_agan_grad_dst", None)
 
 
-def _grad_out(dst, shape, like: Tensor) -> Tensor:
-    """Where a backward kernel should write a parameter gradient.  The FIRST contribution of a backward pass goes straight
-    into the flat buffer (autograd then adopts that view as p.grad); a parameter used more than once per backward (a
-    discriminator sees the real and the fake batch) gets its later contributions in scratch tensors that autograd adds."""
-    if dst is None or dst.written:
-        return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _grad_out(dst, shape, like: Tensor):
+    """-> (buffer the backward kernel writes, accumulate flag for the kernel, value handed back to autograd).
+
+    Without a flat destination: a scratch tensor that autograd accumulates as usual.  With one, the FIRST contribution of a
+    backward pass overwrites the parameter's slice of the flat buffer and autograd adopts a view of it as p.grad; a parameter
+    used again in the same backward (a discriminator sees the real and the fake batch) has the kernel ADD into the slice and
+    autograd gets None for that edge -- no `grad += new` launches, no copies."""
+    if dst is None:
+        t = torch.empty(shape, dtype=torch.float32, device=like.device)
+        return t, 0, t
+    view = dst.flat[dst.offset:dst.offset + dst.numel].view(shape)
+    if dst.written:
+        return view, 1, None
     dst.written = True
-    return dst.flat[dst.offset:dst.offset + dst.numel].view(shape)
+    return view, 0, view
 
 
 class GradDst:
@@ -219,7 +226,7 @@ class _ConvFn(Function):
             dx = torch.empty_like(x)
             _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
         if ctx.needs_input_grad[1]:
-            dw = _grad_out(ctx.wdst, w.shape, x)
+            dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, x)
             lib = L.load()
             nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
             ws, wsp = _ws(nbytes, x)
@@ -227,12 +234,13 @@ class _ConvFn(Function):
             obs = _OBSERVER[0]
             if obs is not None:
                 obs.begin(ctx.kind, "wgrad", gf)
-            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dw), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wsp, nbytes, _stream())
+            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wacc, wsp, nbytes,
+                   _stream())
             if obs is not None:
                 obs.end()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _grad_out(ctx.bdst, (Cout,), x)
-            L.call("agan_bias_grad", _p(dy), _p(db), B, Cout, dy.shape[2] * dy.shape[3], _stream())
+            dbbuf, bacc, db = _grad_out(ctx.bdst, (Cout,), x)
+            L.call("agan_bias_grad", _p(dy), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
         return dx, dw, db, None, None, None, None
 
 
@@ -290,11 +298,14 @@ class _BnActFn(Function):
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dx = torch.empty_like(x)
-        dg, db = _grad_out(ctx.gdst, g.shape, x), _grad_out(ctx.bdst, b.shape, x)
+        dgbuf, gacc, dg = _grad_out(ctx.gdst, g.shape, x)
+        dbbuf, bacc, db = _grad_out(ctx.bdst, b.shape, x)
+        if gacc != bacc:
+            raise L.AganError("BatchNorm weight/bias gradient destinations out of step")
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(B, C, HW)
         ws, wsp = _ws(nbytes, x)
-        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dg), _p(db), B, C, HW,
-               ctx.act, wsp, nbytes, _stream())
+        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
+               ctx.act, gacc, wsp, nbytes, _stream())
         dres = dout if ctx.has_res else None
         return dx, dg, db, dres, None, None, None, None, None, None, None, None, None
 
@@ -387,11 +398,12 @@ class _AttentionFn(Function):
         _, E, T = words.shape
         dctx = _dev(dctx, "attention dctx") if dctx is not None else None
         dattn = _dev(dattn, "attention dattn") if dattn is not None else None
-        dimages, dwords, dw = torch.empty_like(images), torch.empty_like(words), _grad_out(ctx.wdst, w.shape, images)
+        dimages, dwords = torch.empty_like(images), torch.empty_like(words)
+        dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, images)
         nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T)
         ws, wsp = _ws(nbytes, images)
         L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
-               _p(dimages), _p(dwords), _p(dw), B, C, E, T, H * W, wsp, nbytes, _stream())
+               _p(dimages), _p(dwords), _p(dwbuf), B, C, E, T, H * W, wacc, wsp, nbytes, _stream())
         return dimages, dwords, dw, None, None, None
 
 

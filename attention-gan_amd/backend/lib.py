@@ -37,20 +37,20 @@ _SIGNATURES = {
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
     "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, _P, c_size_t, _P]),
     "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
-    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
-    "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_act_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "agan_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "agan_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "agan_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "agan_glu_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "agan_attn_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_attn_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_attn_bwd": (c_int, [_P] * 7 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_attn_bwd": (c_int, [_P] * 7 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "agan_func_attention_fwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_words_loss_save_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "agan_words_loss_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

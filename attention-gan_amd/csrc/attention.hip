@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 // dwords[b,e,t] = sum_c w[c,e] dproj[b,c,t];   dw[c,e] = sum_{b,t} dproj[b,c,t] words[b,e,t]
 __global__ __launch_bounds__(256) void attn_bwd_words_kernel(const float* __restrict__ words, const float* __restrict__ w,
                                                              const float* __restrict__ dproj, float* __restrict__ dwords,
-                                                             float* __restrict__ dw, int B, int C, int E, int T) {
+                                                             float* __restrict__ dw, int B, int C, int E, int T, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nw = B * E * T;
     if (i < nw) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_bwd_words_kernel(const float* __rest
         float s = 0.f;
         for (int b = 0; b < B; ++b)
             for (int t = 0; t < T; ++t) s += dproj[((size_t)b * C + c) * T + t] * words[((size_t)b * E + e) * T + t];
-        dw[j] = s;
+        dw[j] = accumulate ? dw[j] + s : s;
     }
 }
 
@@ -183,7 +183,7 @@ size_t agan_attn_bwd_ws_bytes(int B, int C, int T) { return (size_t)B * C * T * 
 
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw, int B, int C,
-                  int E, int T, int HW, void* ws, size_t ws_bytes, void* stream) {
+                  int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     AGAN_REQUIRE(images && words && w && proj && attn && dimages && dwords && dw && ws, "attn_bwd: null pointer");
     AGAN_REQUIRE(C <= kMaxC && T <= 64, "attn_bwd: nc_in %d / seq_len %d out of range", C, T);
     if (ws_bytes < agan_attn_bwd_ws_bytes(B, C, T)) {
@@ -200,7 +200,7 @@ int agan_attn_bwd(const float* images, const float* words, const float* w, const
     if (T <= 16) hipLaunchKernelGGL((attn_bwd_kernel<16>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
     else if (T <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
     else hipLaunchKernelGGL((attn_bwd_kernel<64>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
-    hipLaunchKernelGGL(attn_bwd_words_kernel, dim3(cdiv(B * E * T + C * E, 256)), dim3(256), 0, st, words, w, dproj, dwords, dw, B, C, E, T);
+    hipLaunchKernelGGL(attn_bwd_words_kernel, dim3(cdiv(B * E * T + C * E, 256)), dim3(256), 0, st, words, w, dproj, dwords, dw, B, C, E, T, accumulate);
     return check_launch("attn_bwd");
 }
 

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 // coef[c] = {mean dz, mean dz*xhat}; dgamma, dbeta
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int C, int Co, int nchunk, int n, bool glu,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ coef) {
+                                                           float* __restrict__ coef, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int pc = (glu && c >= Co) ? c - Co : c;
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
         s += part[((size_t)pc * nchunk + k) * 4 + off];
         q += part[((size_t)pc * nchunk + k) * 4 + off + 1];
     }
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
     coef[2 * c] = (float)(s / n);
     coef[2 * c + 1] = (float)(q / n);
 }
@@ -442,8 +442,8 @@ size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW) {
 }
 
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, void* ws,
-                    size_t ws_bytes, void* stream) {
+                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream) {
     AGAN_REQUIRE(x && dout && mean && invstd && gamma && beta && dx && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_bwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
@@ -461,7 +461,7 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
     if (glu) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_GLU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
     else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, B * HW, glu, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, B * HW, glu, dgamma, dbeta, coef, accumulate);
     const bool vec = (HW & 3) == 0;
     const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
 #define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, coef, dx, B, C, HW)

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
 // 8th slab (4 independent loads in flight), the 8 partial sums meet in LDS.  Deterministic (fixed summation order).
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
                                                         const float* __restrict__ bias, int C, int HW,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int accumulate) {
     __shared__ float4 part[8][32];
     const size_t n4 = n / 4;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
                 a.x += bias[(q / HW) % C]; a.y += bias[((q + 1) / HW) % C];
                 a.z += bias[((q + 2) / HW) % C]; a.w += bias[((q + 3) / HW) % C];
             }
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(out + i * 4);
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
             *reinterpret_cast<float4*>(out + i * 4) = a;
         }
         __syncthreads();
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
         float a = 0.f;
         for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * slab + q];
         if (bias) a += bias[(q / HW) % C];
-        out[q] = a;
+        out[q] = accumulate ? out[q] + a : a;
     }
 }
 
@@ -477,7 +481,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 }
 
 // UP mode: dw[co][ci][a][b] = sum over the (class, tap) pairs that 3x3 tap (a,b) was folded into; dwk is [cls][co][(ci,r,s)]
-__global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int cout, int cin) {
+__global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int cout, int cin,
+                                                              int accumulate) {
     const int K = cin * 4;
     const size_t total = (size_t)cout * cin * 9;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -498,12 +503,12 @@ __global__ __launch_bounds__(256) void unpack_wgrad_up_kernel(const float* __res
                         v += dwk[((size_t)(py * 2 + px) * cout + co) * K + (ci * 4 + r * 2 + q)];
                     }
             }
-        dw[e] = v;
+        dw[e] = accumulate ? dw[e] + v : v;
     }
 }
 
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int C,
-                                                        int HW) {
+                                                        int HW, int accumulate) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     float s = 0.f;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
         for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
     }
     s = block_sum<256>(s, red);
-    if (threadIdx.x == 0) db[c] = s;
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
 }  // namespace
@@ -610,7 +615,7 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
         const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
-                           bias, g.Cout, g.OH * g.OW, out);
+                           bias, g.Cout, g.OH * g.OW, out, 0);
         return check_launch("conv_gather/sum_slabs");
     }
     return AGAN_OK;
@@ -625,7 +630,7 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
 }
 
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
-                    int kh, int kw, int prec, void* ws, size_t ws_bytes, void* stream) {
+                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_wgrad: precision mode %d not built in this version", prec);
@@ -645,7 +650,7 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
         launch_wgrad_small_n(x, dy, part, g, sp, st);
         const size_t n = (size_t)g.Cout * g.K;
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, part, sp.nchunk,
-                           n, sp.slab, (const float*)nullptr, 1, 1, dw);
+                           n, sp.slab, (const float*)nullptr, 1, 1, dw, accumulate);
         return check_launch("conv_wgrad/small_n");
     }
     const WgradPlan p = plan_wgrad(g, up);
@@ -655,9 +660,11 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     }
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
     float* wsf = static_cast<float*>(ws);
-    // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine
+    // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine.
+    // Under `accumulate` an unsplit direct conv also goes through one scratch slab so that the sum pass can add to dw.
+    const bool via_sum = p.psplit > 1 || (accumulate && !up);
     float* reduced = up ? wsf + (p.psplit > 1 ? p.slab * p.psplit : 0) : dw;
-    float* part = p.psplit > 1 ? wsf : reduced;
+    float* part = via_sum ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
 #define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab)
     if (prec == AGAN_PREC_BF16X3) launch_wgrad_bf16x3(x, dy, part, ktab, g, p, st);
@@ -668,23 +675,24 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
 #undef AGAN_WG
     if (int e = check_launch("conv_wgrad")) return e;
     const size_t n = (size_t)p.ncls * g.Cout * g.K;
-    if (p.psplit > 1) {
+    if (via_sum) {
         const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, p.psplit, n, p.slab, (const float*)nullptr, 1, 1, reduced);
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, p.psplit, n, p.slab, (const float*)nullptr, 1, 1, reduced,
+                           (accumulate && !up) ? 1 : 0);
         if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
     }
     if (up) {
         const size_t total = (size_t)g.Cout * g.Cin * 9;
         hipLaunchKernelGGL(unpack_wgrad_up_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st,
-                           reduced, dw, g.Cout, g.Cin);
+                           reduced, dw, g.Cout, g.Cin, accumulate);
         return check_launch("conv_wgrad/unpack");
     }
     return AGAN_OK;
 }
 
-int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, void* stream) {
+int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, int accumulate, void* stream) {
     AGAN_REQUIRE(dy && dbias && B > 0 && C > 0 && HW > 0, "bias_grad: bad argument");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, dbias, B, C, HW);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, dbias, B, C, HW, accumulate);
     return check_launch("bias_grad");
 }
 

@@ -190,8 +190,9 @@ inline WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     p.pchunk = cdiv(ptiles, ps) * 32;
     p.psplit = cdiv(g.Mtot, p.pchunk);
     p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
-    // partial slabs (only when split) + one reduced slab when a tap-combine pass follows
-    const size_t nslabs = (p.psplit > 1 ? p.psplit : 0) + (needs_combine ? 1 : 0);
+    // partial slabs (one even when unsplit: an accumulating call stages its result there) + one reduced slab when a
+    // tap-combine pass follows
+    const size_t nslabs = p.psplit + (needs_combine ? 1 : 0);
     p.ws_bytes = p.slab * nslabs * sizeof(float);
     return p;
 }

@@ -100,11 +100,12 @@ int agan_conv_gather(const float* in, const void* wk, const float* bias, float* 
  * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).
  * Replaces the wgrad half of conv2d backward at the same call sites. */
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
+/* accumulate != 0: dw += gradient (a parameter used twice in one backward, e.g. D on the real and the fake batch). */
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
-                    int kh, int kw, int prec, void* ws, size_t ws_bytes, void* stream);
+                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* dbias[n] = sum_{b,y,x} dy[b,n,y,x]  (bias of nn.Linear / outlogits conv: generator_submodules.py:152, discriminators.py:15) */
-int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, void* stream);
+int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm + activation (utilities/layers.py:66-67,123-124,143-144,164-174; generator_submodules.py:38)
@@ -123,7 +124,7 @@ int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, cons
 /* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU). */
 size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act,
+                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
                     void* ws, size_t ws_bytes, void* stream);
 /* plain activations without BN (first D conv + LeakyReLU layers.py:139-140; tanh generator_submodules.py:137) */
 int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream);
@@ -145,7 +146,7 @@ int agan_attn_fwd(const float* images, const float* words, const float* w, const
 size_t agan_attn_bwd_ws_bytes(int B, int C, int T);
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw,
-                  int B, int C, int E, int T, int HW, void* ws, size_t ws_bytes, void* stream);
+                  int B, int C, int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DAMSM losses: WordsLoss.get_loss (losses/words_loss.py:29-102, which loops func_attention
