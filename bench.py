@@ -61,9 +61,11 @@ class ConvTimer:
         algorithmic = executed * (9.0 / 4.0) if kind == "up" else executed
         tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
         name = f"conv_wgrad_{self.mode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
+        # algorithmic HBM bytes of this call: gathered tensor + produced tensor + weights, each moved once (fp32)
+        nbytes = 4.0 * (g.B * g.Cin * g.IH * g.IW + g.B * g.Cout * g.OH * g.OW + g.Cout * K * (g.OS * g.OS))
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._open = (name, algorithmic, executed, e0)
+        self._open = (name, algorithmic, executed, nbytes, e0)
 
     def end(self):
         if self._open is None:
@@ -75,10 +77,20 @@ class ConvTimer:
 
     def summary(self):
         by = {}
-        for name, fa, fe, e0, e1 in self.records:
-            d = by.setdefault(name, [0, 0.0, 0.0, 0.0])
-            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fa; d[3] += fe
+        for name, fa, fe, nb, e0, e1 in self.records:
+            d = by.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fa; d[3] += fe; d[4] += nb
         return by
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed PMC run (profiles/r01_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 x2 read correction); None if that kernel was not measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)["kernels"].get(kernel, {}).get("traffic")
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def build(dev, batch, HF):
@@ -191,11 +203,12 @@ def main():
         dom = max(summ.items(), key=lambda kv: kv[1][1]) if summ else None
         roofline = None
         if dom:
-            name, (n, ms, falg, fexec) = dom
+            name, (n, ms, falg, fexec, nbytes) = dom
             achieved = falg / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": measured_traffic(name),
+                        "algorithmic_bytes_per_launch": round(nbytes / n),
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),
                         "share_of_step_time": round(ms / (elapsed * 1e3), 3)}
         line = {
