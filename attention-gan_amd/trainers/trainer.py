@@ -183,3 +183,62 @@ class GanTrainStep(ModelTrainer):
             self.damsm_losses.append(out["w_loss"] + out["s_loss"])
         out["fake_imgs"] = [f.detach() for f in fakes]
         return out
+
+    # -- checkpoint / resume (the reference only saves, and its four `Adam` objects share one Adam.pkl) --
+    def state_dict(self) -> Dict:
+        return {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
+                "g_optim": self.g_opt.state_dict(), "d_optims": [o.state_dict() for o in self.d_opts]}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        self.G.load_state_dict(sd["generator"])
+        self.g_opt.load_state_dict(sd["g_optim"])
+        for d, o, ds, os_ in zip(self.Ds, self.d_opts, sd["discriminators"], sd["d_optims"]):
+            d.load_state_dict(ds)
+            o.load_state_dict(os_)
+
+    @torch.no_grad()
+    def generate_images(self, word_embs: Tensor, sent_embs: Tensor, lengths, noise: Optional[Tensor] = None) -> List[Tensor]:
+        """Sampling path of train.py:154-158 / test.py:77-87: eval-mode generator forward (running BatchNorm statistics),
+        images mapped from [-1,1] to [0,1].  Same kernels as training, forward only."""
+        was_training = self.G.training
+        self.G.eval()
+        try:
+            b = word_embs.shape[0]
+            if noise is None:
+                noise = self._make_noise(b, self.G.z_dim)
+            fakes, _, _, _ = self.G(noise, sent_embs, word_embs, self._make_mask(lengths))
+            return self._denormalise_multiple(fakes)
+        finally:
+            self.G.train(was_training)
+
+
+class DAMSMTrainStep(ModelTrainer):
+    """One batch of DAMSMTrainer.pretrain_damsm (pretrain_damsm.py:114-134): image encoder on the 256x256 image, text encoder
+    on the captions, words + sentence loss (HIP kernels), clip_grad_norm_(RNN, 0.25), one Adam(lr 2e-3, betas (0.5, 0.999))
+    over the RNN parameters and the image encoder's trainable heads.  The two encoders are stock PyTorch-ROCm modules."""
+
+    def __init__(self, rnn: Module, cnn: Module, lr: float = 2e-3, rnn_grad_clip: float = 0.25, gamma1: float = 4.0,
+                 gamma2: float = 5.0, gamma3: float = 10.0, wlambda: float = 5.0, slambda: float = 5.0):
+        super().__init__()
+        self.rnn, self.cnn, self.clip = rnn, cnn, rnn_grad_clip
+        params = list(rnn.parameters()) + [p for p in cnn.parameters() if p.requires_grad]
+        self.optim = torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999))
+        dev = next(rnn.parameters()).device
+        self.words_loss = WordsLoss(dev, gamma1, gamma2, gamma3, wlambda)
+        self.sent_loss = SentenceLoss(dev, gamma3, slambda)
+        self.loss_history: List = []
+
+    def step(self, captions: Tensor, lengths, class_ids, img256: Tensor) -> Dict[str, Tensor]:
+        b = captions.shape[0]
+        labels = self._make_match_labels(b)
+        words_features, sent_code = self.cnn(img256)
+        word_embs, sent_embs = self.rnn(captions, lengths)
+        self.optim.zero_grad()
+        wloss, _ = self.words_loss.get_loss(words_features, word_embs, labels, lengths, class_ids)
+        sloss = self.sent_loss.get_loss(sent_code, sent_embs, labels, class_ids)
+        loss = wloss + sloss
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.rnn.parameters(), self.clip)
+        self.optim.step()
+        self.loss_history.append(loss.detach())
+        return {"loss": loss.detach(), "w_loss": wloss.detach(), "s_loss": sloss.detach()}

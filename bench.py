@@ -93,7 +93,7 @@ def measured_traffic(kernel):
         return None
 
 
-def build(dev, batch, HF):
+def build(dev, batch, HF, encoder="standin"):
     GEN = importlib.import_module("attention-gan_amd.networks.generator")
     DISC = importlib.import_module("attention-gan_amd.networks.discriminators")
     ENC = importlib.import_module("attention-gan_amd.networks.cnn_encoder")
@@ -101,8 +101,9 @@ def build(dev, batch, HF):
     torch.manual_seed(0)      # identical initial weights on every rank (and broadcast from rank 0 on top)
     G = GEN.Generator(GF, EMB, Z, COND).to(dev)
     Ds = [DISC.Disc64(DF).to(dev), DISC.Disc128(DF).to(dev), DISC.Disc256(DF).to(dev)]
-    enc = ENC.StandInImageEncoder(EMB).to(dev)
+    enc = (ENC.StandInImageEncoder(EMB) if encoder == "standin" else ENC.CNNEncoder(EMB)).to(dev)
     enc.freeze_all_weights()
+    enc.eval()                     # the reference loads it with _load_weights(), which puts it in eval mode (trainer.py:124)
     return TR.GanTrainStep(G, Ds, enc)
 
 
@@ -148,6 +149,9 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
                     help="MFMA mode of the conv engine: f32 = exact fp32 products (parity mode, default); bf16x3 = 3-term bf16 split")
+    ap.add_argument("--image-encoder", choices=["standin", "inception"], default="standin",
+                    help="frozen DAMSM image encoder plug-in: 'standin' = contract-only stub (SURVEY §8d prices the hot path without "
+                         "the third-party trunk); 'inception' = Inception-v3-shaped trunk on stock MIOpen convs, random weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     args = ap.parse_args()
@@ -168,7 +172,7 @@ def main():
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     LIB = importlib.import_module("attention-gan_amd.backend.lib")
     HF.set_precision(LIB.PREC_F32 if args.precision == "f32" else LIB.PREC_BF16X3)
-    step = build(dev, args.batch, HF)
+    step = build(dev, args.batch, HF, args.image_encoder)
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
     timer = ConvTimer(args.precision)
     HF.set_launch_observer(timer)
@@ -220,7 +224,9 @@ def main():
             "config": {"workload": "full 3-stage AttnGAN 64->128->256 train step: G + 3xD updates + word attention + DAMSM words/sentence "
                                    "loss + KL + 4x fused Adam (BASELINE.json configs[2])",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "gf_dim": GF, "df_dim": DF, "emb_dim": EMB,
-                       "seq_len": T, "image_encoder": "frozen stand-in plug-in (pool+projection); Inception-v3 trunk is SURVEY row f1",
+                       "seq_len": T, "image_encoder": ("frozen stand-in plug-in (pool+projection): the timed step is the hot path of SURVEY §8d, which "
+                                                       "prices the third-party trunk separately" if args.image_encoder == "standin" else
+                                                       "frozen Inception-v3-shaped trunk (random weights) on stock MIOpen convs, fwd + dgrad in the timed step"),
                        "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}", "losses_finite": finite},
             "roofline": roofline,
         }
