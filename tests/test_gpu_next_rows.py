@@ -118,3 +118,74 @@ def test_inception_shaped_encoder_contract():
     assert x.grad is not None and torch.isfinite(x.grad).all()
     trainable = [k for k, p in m.named_parameters() if p.requires_grad]
     assert sorted(trainable) == ["emb_cnn_code.bias", "emb_cnn_code.weight", "emb_features.weight"]
+
+
+def test_config1_stage1_batch64_vs_oracle():
+    """BASELINE.json configs[1]: stage-1 only (CA-net + gen1 + img_out1 + Disc64) at batch 64, forward and backward vs the oracle."""
+    torch.manual_seed(1)
+    G = GEN.Generator(8, 32, 16, 16).to(DEV)
+    D = DISC.Disc64(8).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    B = 64
+    noise, sent, eps = (torch.randn(B, n, generator=g) for n in (16, 32, 16))
+    gp = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    dp = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    for k in list(gp) + list(dp):
+        pass
+    keys = [k for k in gp if k.startswith(("vae.", "gen1.", "img_out1.")) and k.endswith((".weight", ".bias"))]
+    for k in keys:
+        gp[k].requires_grad_(True)
+    mu, logvar = O.vae_encode(sent, gp)
+    h = O.gen_initial_stage(noise, O.vae_reparam(mu, logvar, eps), gp, "gen1")
+    img_ref = O.gen_make_image(h, gp, "img_out1")
+    loss_ref = O.ns_gen_loss(O.disc_forward(dp, img_ref, 64)) + O.kl_loss(mu, logvar)
+    grads_ref = dict(zip(keys, torch.autograd.grad(loss_ref, [gp[k] for k in keys])))
+    cond, mu_d, lv_d = G.vae(sent.to(DEV), eps.to(DEV))
+    img = G.img_out1(G.gen1(noise.to(DEV), cond))
+    KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
+    GL = importlib.import_module("attention-gan_amd.losses.gen_loss").NonSaturatingGenLoss()
+    loss = GL.get_loss(D, img) + KL(mu_d, lv_d)
+    loss.backward()
+    assert_close(img, img_ref, RTOL, "stage-1 image B=64")
+    assert_close(loss, loss_ref, RTOL, "loss")
+    named = dict(G.named_parameters())
+    for k in keys:
+        assert_close(named[k].grad, grads_ref[k], RTOL, f"grad {k}")
+
+
+def test_config4_stage4_extension_vs_oracle_composition():
+    """BASELINE.json configs[4]: 4th stage (512x512) + Disc512, small widths: forward vs the oracle's primitives composed alike."""
+    S4 = importlib.import_module("attention-gan_amd.networks.stage4")
+    torch.manual_seed(2)
+    G = S4.Generator4(4, 16, 8, 8).to(DEV)
+    D = S4.Disc512(2).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    B, Tn = 2, 4
+    noise, sent, eps, words = torch.randn(B, 8, generator=g), torch.randn(B, 16, generator=g), torch.randn(B, 8, generator=g), torch.randn(B, 16, Tn, generator=g)
+    lens = [4, 2]
+    gp = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    dp = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    mask = O.make_mask(lens)
+    fakes_ref, _, _, _ = O.generator_forward(gp, noise, sent, words, mask, eps)
+    # 4th stage by hand from the oracle primitives
+    mu, logvar = O.vae_encode(sent, gp)
+    h = O.gen_initial_stage(noise, O.vae_reparam(mu, logvar, eps), {k: v.clone() for k, v in gp.items()}, "gen1")
+    gp2 = {k: v.clone() for k, v in gp.items()}
+    h = O.gen_initial_stage(noise, O.vae_reparam(mu, logvar, eps), gp2, "gen1")
+    for st in ("gen2", "gen3", "gen4"):
+        h, _ = O.gen_next_stage(h, words, mask, gp2, st)
+    img512_ref = O.gen_make_image(h, gp2, "img_out4")
+    y = O.encode_image_by_16times(img512_ref, dp, "img_code_s16")
+    for n in ("img_code_s32", "img_code_s64", "img_code_s128"):
+        y = O.down_block(y, dp, n)
+    for n in ("img_code_s128_1", "img_code_s128_2", "img_code_s128_3"):
+        y = O.block3x3_leak(y, dp, n)
+    p_ref = torch.sigmoid(torch.nn.functional.conv2d(y, dp["outlogits.0.weight"], dp["outlogits.0.bias"], stride=4)).view(-1)
+    fakes, attns, _, _ = G(noise.to(DEV), sent.to(DEV), words.to(DEV), mask.to(DEV), eps.to(DEV))
+    assert [tuple(f.shape[-2:]) for f in fakes] == [(64, 64), (128, 128), (256, 256), (512, 512)] and len(attns) == 3
+    assert_close(fakes[2], fakes_ref[2], RTOL, "256 image")
+    assert_close(fakes[3], img512_ref, RTOL, "512 image")
+    p = D(fakes[3])
+    assert_close(p, p_ref, RTOL, "Disc512 output")
+    p.sum().backward()                                                                     # backward runs through the extension
+    assert all(torch.isfinite(q.grad).all() for q in G.parameters() if q.grad is not None)
