@@ -270,20 +270,20 @@ class _BnActFn(Function):
         HW = x.numel() // (B * C)
         g, b = _dev(gamma.detach(), "bn weight"), _dev(beta.detach(), "bn bias")
         lib = L.load()
-        if training:
-            mean = torch.empty(C, dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            nbytes = lib.agan_bn_stats_ws_bytes(B, C, HW)
-            ws, wsp = _ws(nbytes, x)
-            L.call("agan_bn_stats", _p(x), B, C, HW, float(eps), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-                   _p(nbt), float(momentum), wsp, nbytes, _stream())
-        else:
-            mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
         co = C // 2 if act == L.ACT_GLU else C
         out = torch.empty((B, co) + tuple(shape[2:]), dtype=torch.float32, device=x.device)
         res = _dev(residual, "bn residual") if residual is not None else None
-        L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            nbytes = lib.agan_bn_train_fwd_ws_bytes(B, C, HW)
+            ws, wsp = _ws(nbytes, x)
+            L.call("agan_bn_train_fwd", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
+                   _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, wsp, nbytes, _stream())
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+            L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
         ctx.save_for_backward(x, g, b, mean, invstd)
         ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst = act, training, residual is not None, gdst, bdst
         return out

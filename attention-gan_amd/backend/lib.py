@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libagan_hip.so")
+LIB_PATH = os.environ.get("AGAN_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libagan_hip.so")   # AGAN_LIB: kernel A/B builds
 
 # enums of include/agan.h
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
@@ -41,6 +41,8 @@ _SIGNATURES = {
     "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "agan_bn_train_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "agan_bn_train_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_act_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),

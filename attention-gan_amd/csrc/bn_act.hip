@@ -384,6 +384,166 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// small tensors (B*HW <= kSmallN per channel: the 4x4 / 8x8 / 16x16 layers): statistics + normalise + activation in ONE launch,
+// one workgroup per (output) channel with the channel's values held in registers between the two phases
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSmallN = 8192;
+constexpr int kSmallPer = kSmallN / 256;
+
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double (*red)[4]) {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a; red[1][w] = b; }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ res, float* __restrict__ out, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           int64_t* __restrict__ nbt, int B, int C, int HW, float eps, float momentum) {
+    __shared__ double red[2][4];
+    constexpr bool GLU = ACT == AGAN_ACT_GLU;
+    const int Co = GLU ? C / 2 : C;
+    const int c = blockIdx.x, n = B * HW;
+    if (c == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    float va[kSmallPer], vg[GLU ? kSmallPer : 1];
+    double s = 0.0, q = 0.0, sg = 0.0, qg = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+        const int i = threadIdx.x + j * 256;
+        va[j] = 0.f;
+        if (GLU) vg[j] = 0.f;
+        if (i < n) {
+            const int b = i / HW, p = i - b * HW;
+            const size_t xi = ((size_t)b * C + c) * HW + p;
+            va[j] = x[xi];
+            s += va[j];
+            q += (double)va[j] * va[j];
+            if (GLU) {
+                vg[j] = x[xi + (size_t)Co * HW];
+                sg += vg[j];
+                qg += (double)vg[j] * vg[j];
+            }
+        }
+    }
+    block_sum2_d(s, q, red);
+    const double m = s / n;
+    double var = q / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    float mgf = 0.f, isg = 0.f;
+    double mg = 0.0, varg = 0.0;
+    if (GLU) {
+        block_sum2_d(sg, qg, red);
+        mg = sg / n;
+        varg = qg / n - mg * mg;
+        varg = varg < 0.0 ? 0.0 : varg;
+        mgf = (float)mg;
+        isg = (float)(1.0 / sqrt(varg + (double)eps));
+    }
+    if (threadIdx.x == 0) {
+        const double ub = n > 1 ? (double)n / (n - 1) : 1.0;
+        mean[c] = (float)m;
+        invstd[c] = is;
+        if (rmean) {
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * ub);
+        }
+        if (GLU) {
+            mean[c + Co] = mgf;
+            invstd[c + Co] = isg;
+            if (rmean) {
+                rmean[c + Co] = (float)((1.0 - momentum) * rmean[c + Co] + momentum * mg);
+                rvar[c + Co] = (float)((1.0 - momentum) * rvar[c + Co] + momentum * varg * ub);
+            }
+        }
+    }
+    const float sa = gamma[c] * is, ta = beta[c] - (float)m * sa;
+    float sgs = 0.f, tg = 0.f;
+    if (GLU) { sgs = gamma[c + Co] * isg; tg = beta[c + Co] - mgf * sgs; }
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < n) {
+            const int b = i / HW, p = i - b * HW;
+            const size_t oi = ((size_t)b * Co + c) * HW + p;
+            float z = va[j] * sa + ta;
+            if (GLU) z *= sigmoidf_(vg[j] * sgs + tg);
+            else if (ACT == AGAN_ACT_LRELU) z = z >= 0.f ? z : z * kSlope;
+            if (!GLU && ACT == AGAN_ACT_NONE && res) z += res[oi];
+            out[oi] = z;
+        }
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int B, int C, int HW, int accumulate) {
+    __shared__ double red[2][4];
+    constexpr bool GLU = ACT == AGAN_ACT_GLU;
+    const int Co = GLU ? C / 2 : C;
+    const int c = blockIdx.x, n = B * HW;
+    const Affine a = affine_of(mean, invstd, gamma, beta, c);
+    const Affine g = GLU ? affine_of(mean, invstd, gamma, beta, c + Co) : a;
+    const float ma = mean[c], ia = invstd[c];
+    const float mg = GLU ? mean[c + Co] : 0.f, ig = GLU ? invstd[c + Co] : 0.f;
+    float xa[kSmallPer], za[kSmallPer], xg[GLU ? kSmallPer : 1], zg[GLU ? kSmallPer : 1];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+        const int i = threadIdx.x + j * 256;
+        xa[j] = 0.f; za[j] = 0.f;
+        if (GLU) { xg[j] = 0.f; zg[j] = 0.f; }
+        if (i < n) {
+            const int b = i / HW, p = i - b * HW;
+            const size_t xi = ((size_t)b * C + c) * HW + p;
+            xa[j] = x[xi];
+            const float d = dout[((size_t)b * Co + c) * HW + p];
+            float xgv = 0.f;
+            if (GLU) { xgv = x[xi + (size_t)Co * HW]; xg[j] = xgv; }
+            float dza, dzg;
+            dz_of<ACT>(xa[j], xgv, d, a, g, dza, dzg);
+            za[j] = dza;
+            s0 += dza;
+            s1 += (double)dza * ((xa[j] - ma) * ia);
+            if (GLU) {
+                zg[j] = dzg;
+                s2 += dzg;
+                s3 += (double)dzg * ((xgv - mg) * ig);
+            }
+        }
+    }
+    block_sum2_d(s0, s1, red);
+    if (GLU) block_sum2_d(s2, s3, red);
+    if (threadIdx.x == 0) {
+        dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
+        dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
+        if (GLU) {
+            dbeta[c + Co] = accumulate ? dbeta[c + Co] + (float)s2 : (float)s2;
+            dgamma[c + Co] = accumulate ? dgamma[c + Co] + (float)s3 : (float)s3;
+        }
+    }
+    const float c0 = (float)(s0 / n), c1 = (float)(s1 / n), g0 = (float)(s2 / n), g1 = (float)(s3 / n);
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < n) {
+            const int b = i / HW, p = i - b * HW;
+            const size_t xi = ((size_t)b * C + c) * HW + p;
+            dx[xi] = a.s * (za[j] - c0 - (xa[j] - ma) * ia * c1);
+            if (GLU) dx[xi + (size_t)Co * HW] = g.s * (zg[j] - g0 - (xg[j] - mg) * ig * g1);
+        }
+    }
+}
+
 int ew_blocks(size_t work) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(work, 256), 256 * 8)); }
 
 }  // namespace
@@ -452,6 +612,15 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
         return AGAN_EWORKSPACE;
     }
     hipStream_t st = as_stream(stream);
+    if (HW > 1 && (long long)B * HW <= kSmallN) {
+        const int Cb = act == AGAN_ACT_GLU ? C / 2 : C;
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Cb), dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, accumulate)
+        if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
+        else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
+        else AGAN_L(AGAN_ACT_NONE);
+#undef AGAN_L
+        return check_launch("bn_act_bwd/small");
+    }
     const int nchunk = bwd_chunks(B, C, HW);
     const bool glu = act == AGAN_ACT_GLU;
     const int Co = glu ? C / 2 : C;
@@ -509,6 +678,33 @@ int agan_glu_bwd(const float* x, const float* dout, float* dx, int B, int C, int
     AGAN_REQUIRE(x && dout && dx && B > 0 && C > 0 && HW > 0 && C % 2 == 0, "glu_bwd: bad argument");
     hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_blocks((size_t)B * (C / 2) * HW)), dim3(256), 0, as_stream(stream), x, dout, dx, B, C, HW);
     return check_launch("glu_bwd");
+}
+
+size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW) {
+    if (HW > 1 && (long long)B * HW <= kSmallN) return 0;
+    return agan_bn_stats_ws_bytes(B, C, HW);
+}
+
+int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
+                      float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
+                      float momentum, int act, void* ws, size_t ws_bytes, void* stream) {
+    AGAN_REQUIRE(x && gamma && beta && out && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_train_fwd: bad argument");
+    AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_train_fwd: activation %d", act);
+    AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
+    AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_train_fwd: residual only with ACT_NONE");
+    AGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running_mean/var must come together");
+    if (HW > 1 && (long long)B * HW <= kSmallN) {
+        hipStream_t st = as_stream(stream);
+        const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, x, gamma, beta, residual, out, mean, invstd, running_mean, running_var, nbt, B, C, HW, eps, momentum)
+        if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
+        else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
+        else AGAN_L(AGAN_ACT_NONE);
+#undef AGAN_L
+        return check_launch("bn_train_fwd/small");
+    }
+    if (int e = agan_bn_stats(x, B, C, HW, eps, mean, invstd, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream)) return e;
+    return agan_bn_act_fwd(x, mean, invstd, gamma, beta, residual, out, B, C, HW, act, stream);
 }
 
 }  // extern "C"

@@ -38,12 +38,18 @@ __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int
 // ================================================================================================
 // forward / dgrad gather kernel
 // ================================================================================================
+#ifndef AGAN_GATHER_BK
+#define AGAN_GATHER_BK 16
+#endif
+#ifndef AGAN_GATHER_WAVES
+#define AGAN_GATHER_WAVES 3
+#endif
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+__global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                const int2* __restrict__ ktab, const Geom g, const int ksplit,
                                                                const int kchunk, const size_t slab) {
-    constexpr int BK = 16;
+    constexpr int BK = AGAN_GATHER_BK;
     constexpr int NG = 256 / BM;       // wave-uniform k groups for the pixel-major A loads
     constexpr int AK = BK / NG;        // k rows per thread per tile
     constexpr int NB4 = BK * BN / 4;   // float4s in a weight tile
@@ -147,7 +153,9 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
     // FULL = steady state (no conditionals, so the compiler's waitcnt bookkeeping stays exact across iterations)
     auto step = [&](auto full, auto cur, auto nxt, int kt, int buf) {
         constexpr bool FULL = decltype(full)::value;
+#if !defined(AGAN_ABLATE) || AGAN_ABLATE < 1
         if (FULL || kt + 2 < nkt) load_tile(cur, kt + 2);
+#endif
         // operand fragments are read one k-step ahead of the MFMAs that consume them (LDS latency off the critical path)
         float av[2][TM], bv[2][TN];
 #pragma unroll
@@ -172,8 +180,12 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const float* __
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
+#if !defined(AGAN_ABLATE) || AGAN_ABLATE < 2
         if (FULL || kt + 1 < nkt) store_tile(nxt, buf ^ 1);
+#endif
+#if !defined(AGAN_ABLATE) || AGAN_ABLATE < 3
         __syncthreads();
+#endif
     };
 
     if (nkt > 0) load_tile(S0{}, 0);

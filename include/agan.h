@@ -121,6 +121,13 @@ int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, 
 /* y = act(gamma*(x-mean)*invstd+beta) [+ residual].  GLU halves the channels (out has C/2).  residual may be NULL. */
 int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                     const float* residual, float* out, int B, int C, int HW, int act, void* stream);
+/* Training-mode forward in one call: batch statistics (written to mean/invstd for the backward, folded into the running
+ * statistics) + normalise + activation.  Tensors with B*HW <= 8192 per channel run as ONE launch (a workgroup per channel
+ * keeps the channel in registers between the two phases); larger ones as agan_bn_stats + agan_bn_act_fwd. */
+size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW);
+int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
+                      float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, int HW,
+                      float eps, float momentum, int act, void* ws, size_t ws_bytes, void* stream);
 /* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU). */
 size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
