@@ -2,6 +2,7 @@
 train.py:109-151 as a reusable object (`GanTrainStep`) with flat-buffer Adam and overlapped gradient all-reduce."""
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from datetime import datetime
@@ -135,6 +136,13 @@ class GanTrainStep(ModelTrainer):
         self.g_losses: List = []
         self.d_losses: List = []
         self.damsm_losses: List = []
+        self.overlap_discriminators = True
+        self._streams: List = []
+
+    def _d_streams(self, n: int, device) -> List:
+        if len(self._streams) != n:
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return self._streams
 
     def step(self, word_embs: Tensor, sent_embs: Tensor, lengths, class_ids, real_imgs: Sequence[Tensor],
              noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -146,29 +154,57 @@ class GanTrainStep(ModelTrainer):
         fakes, _attn, mu, logvar = self.G(noise, sent_embs, word_embs, mask, eps)
         out: Dict[str, Tensor] = {}
         # ---- discriminator updates (train.py:123-130) ----
+        # The three updates are independent of each other (each D has its own weights, optimiser and images), so each runs on
+        # its own HIP stream: the deep 4x4/8x8 layers of one discriminator (tiny grids) overlap the wide early layers of another.
+        # Autograd replays each backward on the stream its forward ran on.
+        main = torch.cuda.current_stream() if fakes[0].is_cuda else None
+        streams = self._d_streams(len(self.Ds), fakes[0].device) if (main is not None and self.overlap_discriminators) else None
         for i, (d, opt, bk) in enumerate(zip(self.Ds, self.d_opts, self.d_buckets)):
-            opt.zero_grad()
-            bk.arm()
-            loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
-            loss.backward()
-            opt.step(bk.finish())
-            out[f"d_loss{i}"] = loss.detach()
+            if streams is not None:
+                streams[i].wait_stream(main)
+                ctx = torch.cuda.stream(streams[i])
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                opt.zero_grad()
+                bk.arm()
+                loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
+                loss.backward()
+                opt.step(bk.finish())
+                out[f"d_loss{i}"] = loss.detach()
+        if streams is not None:
+            for st in streams:
+                main.wait_stream(st)
         # ---- generator update (train.py:132-151) ----
         self.g_opt.zero_grad()
         self.g_buckets.arm()
         for d in self.Ds:
             d.requires_grad_(False)
-        total = None
+        # adversarial terms: one stream per discriminator again (forward here, autograd replays the dgrad chains on the same
+        # streams); the DAMSM branch (image encoder + words/sentence loss) rides on the last discriminator's stream
+        terms = []
         for i, d in enumerate(self.Ds):
-            gl = self.gen_loss.get_loss(d, fakes[i])
-            total = gl if total is None else total + gl
-            out[f"g_loss{i}"] = gl.detach()
-            if i == len(self.Ds) - 1 and self.image_encoder is not None:
-                regions, code = self.image_encoder(fakes[i])
-                wl, _ = self.words_loss.get_loss(regions, word_embs, labels, lengths, class_ids)
-                sl = self.sent_loss.get_loss(code, sent_embs, labels, class_ids)
-                total = total + wl + sl
-                out["w_loss"], out["s_loss"] = wl.detach(), sl.detach()
+            if streams is not None:
+                streams[i].wait_stream(main)
+                ctx = torch.cuda.stream(streams[i])
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                gl = self.gen_loss.get_loss(d, fakes[i])
+                terms.append(gl)
+                out[f"g_loss{i}"] = gl.detach()
+                if i == len(self.Ds) - 1 and self.image_encoder is not None:
+                    regions, code = self.image_encoder(fakes[i])
+                    wl, _ = self.words_loss.get_loss(regions, word_embs, labels, lengths, class_ids)
+                    sl = self.sent_loss.get_loss(code, sent_embs, labels, class_ids)
+                    terms += [wl, sl]
+                    out["w_loss"], out["s_loss"] = wl.detach(), sl.detach()
+        if streams is not None:
+            for st in streams:
+                main.wait_stream(st)
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
         kl = KL_loss(mu, logvar)
         total = total + kl
         out["kl"], out["g_total"] = kl.detach(), total.detach()
