@@ -300,7 +300,7 @@ void launch_gather(const float* in, const float* wk, const float* bias, float* d
 template <int BI, int BJ>
 __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ dst, const int2* __restrict__ ktab, const Geom g,
-                                                              const int psplit, const int pchunk, const size_t slab) {
+                                                              const int psplit, const int pchunk, const size_t slab, const int accumulate) {
     constexpr int BP = 32, LDP = 33;   // +1 pad: MFMA operand reads walk the row index across lanes
     constexpr int XR = BI / 8, YR = BJ / 8;   // rows per thread per tile
     constexpr int TI = BI / 64, TJ = BJ / 64;
@@ -425,7 +425,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = j0 + wj * (BJ / 2) + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                buf_store(ro, ((i < g.K) & (n < g.Cout)) ? (unsigned)(n * g.K + i) * 4u : kOOB, acc[tj][ti][r]);
+                const unsigned off = ((i < g.K) & (n < g.Cout)) ? (unsigned)(n * g.K + i) * 4u : kOOB;
+                float v = acc[tj][ti][r];
+                if (accumulate) v += buf_load(ro, off);        // unsplit second use of a parameter: add into the flat gradient
+                buf_store(ro, off, v);
             }
         }
 }
@@ -674,11 +677,13 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     float* wsf = static_cast<float*>(ws);
     // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine.
     // Under `accumulate` an unsplit direct conv also goes through one scratch slab so that the sum pass can add to dw.
-    const bool via_sum = p.psplit > 1 || (accumulate && !up);
+    // an unsplit direct conv accumulates in its own epilogue (f32 kernels); every other case goes through the slab sum
+    const int acc_in_kernel = (accumulate && !up && p.psplit == 1 && prec == AGAN_PREC_F32) ? 1 : 0;
+    const bool via_sum = p.psplit > 1 || (accumulate && !up && !acc_in_kernel);
     float* reduced = up ? wsf + (p.psplit > 1 ? p.slab * p.psplit : 0) : dw;
     float* part = via_sum ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
-#define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab)
+#define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab, acc_in_kernel)
     if (prec == AGAN_PREC_BF16X3) launch_wgrad_bf16x3(x, dy, part, ktab, g, p, st);
     else if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
     else if (p.bi == 128) AGAN_WG(128, 64);
