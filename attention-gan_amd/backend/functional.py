@@ -557,7 +557,10 @@ class _WordsLossFn(Function):
 
 
 def words_loss(feat, wemb, cap_lens, class_ids, gamma1, gamma2, gamma3, wlambda):
-    lens = torch.as_tensor(cap_lens).to(device=feat.device, dtype=torch.int64).contiguous()
+    if isinstance(cap_lens, Tensor) and cap_lens.is_cuda and cap_lens.dtype == torch.int64:
+        lens = cap_lens.contiguous()                       # already resident: no host round trip (HIP-graph capturable)
+    else:
+        lens = torch.as_tensor(cap_lens).to(device=feat.device, dtype=torch.int64).contiguous()
     return _WordsLossFn.apply(feat, wemb, lens, _ids(class_ids, feat.device), float(gamma1), float(gamma2), float(gamma3),
                               float(wlambda))
 
@@ -592,11 +595,15 @@ def sentence_loss(cnn_code, rnn_code, class_ids, gamma3, slambda, eps=1e-8):
 # --------------------------------------------------------------------------------------------------------------
 # fused Adam on a flat buffer
 # --------------------------------------------------------------------------------------------------------------
-def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float, beta1: float,
+def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_state: Tensor, lr: float, beta1: float,
                beta2: float, eps: float, grad_scale: float = 1.0) -> None:
+    """One fused Adam step over a flat buffer.  `step_state` is the optimiser's 4-element int32 device tensor: the kernel
+    advances the step count in it and derives the bias corrections on the device (graph-replay safe)."""
     for t in (param, grad, exp_avg, exp_avg_sq):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise L.AganError("adam_step_: flat contiguous float32 device buffers required")
-    L.call("agan_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step), float(lr),
+    if not step_state.is_cuda or step_state.dtype != torch.int32 or step_state.numel() < 4:
+        raise L.AganError("adam_step_: step_state must be an int32 device tensor of 4 elements")
+    L.call("agan_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(step_state), float(lr),
            float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
     bump_weight_epoch()

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "agan_kl_loss": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "agan_reparam_fwd": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "agan_reparam_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
-    "agan_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_double, c_double, c_double, c_double, c_float, _P]),
+    "agan_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_double, c_double, c_double, c_double, c_float, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -386,10 +386,10 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);
     if (T <= 16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        static const hipError_t attr_16_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>()); (void)attr_16_;
         hipLaunchKernelGGL((words_pair_fwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        static const hipError_t attr_32_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>()); (void)attr_32_;
         hipLaunchKernelGGL((words_pair_fwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
     }
     hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, lambda, loss, save, B);
@@ -403,10 +403,10 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);     // dfeat / dwemb must be zero-initialised by the caller (they are accumulated with atomics)
     if (T <= 16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        static const hipError_t attr_16_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>()); (void)attr_16_;
         hipLaunchKernelGGL((words_pair_bwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        static const hipError_t attr_32_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>()); (void)attr_32_;
         hipLaunchKernelGGL((words_pair_bwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
     }
     return check_launch("words_loss_bwd");
@@ -443,10 +443,10 @@ int agan_func_attention_fwd(const float* query, const float* context, float gamm
     AGAN_REQUIRE(B >= 1 && D >= 1 && D <= kNT && S >= 1 && S <= kNT && L >= 1 && L <= 32, "func_attention: shape out of range");
     hipStream_t st = as_stream(stream);
     if (L <= 16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        static const hipError_t attr_16_ = hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>()); (void)attr_16_;
         hipLaunchKernelGGL((func_attn_fwd_kernel<16>), dim3(B), dim3(kNT), pair_smem_bytes<16>(), st, query, context, gamma1, scale, wctx, attn, D, L, S);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        static const hipError_t attr_32_ = hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>()); (void)attr_32_;
         hipLaunchKernelGGL((func_attn_fwd_kernel<32>), dim3(B), dim3(kNT), pair_smem_bytes<32>(), st, query, context, gamma1, scale, wctx, attn, D, L, S);
     }
     return check_launch("func_attention_fwd");

@@ -81,9 +81,20 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
 }
 
 // torch.optim.Adam single-tensor update, written for one flat buffer (train.py:78-80)
+// step counter and bias corrections live in device memory so that a captured HIP graph advances them on every replay:
+// state[0] = step (as float bits of an int), coef[0] = lr / (1 - beta1^t), coef[1] = 1 / sqrt(1 - beta2^t)
+__global__ void adam_tick_kernel(int* __restrict__ step, float* __restrict__ coef, double lr, double b1, double b2) {
+    const int t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+    coef[0] = (float)(lr / bc1);
+    coef[1] = (float)(1.0 / sqrt(bc2));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, size_t n, float lr_c, float b1, float b2, float omb1, float omb2,
-                                                   float eps, float inv_sqrt_bc2, float gscale) {
+                                                   float* __restrict__ v, size_t n, const float* __restrict__ coef, float b1, float b2,
+                                                   float omb1, float omb2, float eps, float gscale) {
+    const float lr_c = coef[0], inv_sqrt_bc2 = coef[1];
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
@@ -146,15 +157,17 @@ int agan_reparam_bwd(const float* logvar, const float* eps, const float* dc, flo
     return check_launch("reparam_bwd");
 }
 
-int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, double lr, double beta1,
-                   double beta2, double eps, float grad_scale, void* stream) {
-    AGAN_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "adam_step: bad argument");
-    // scalars are rounded to fp32 exactly where torch.optim.Adam rounds them (python doubles -> float tensor ops)
-    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
-    const float lr_c = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int32_t* step_state, double lr,
+                   double beta1, double beta2, double eps, float grad_scale, void* stream) {
+    AGAN_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_state && n > 0, "adam_step: bad argument");
+    // step_state: 4 x 4 bytes of device memory owned by the optimiser: [0] int step count (incremented here), [2],[3] float
+    // bias-correction coefficients.  Scalars are rounded to fp32 exactly where torch.optim.Adam rounds them.
+    hipStream_t st = as_stream(stream);
+    float* coef = reinterpret_cast<float*>(step_state + 2);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_state, coef, lr, beta1, beta2);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n / 4 + 1, 256), 2048));
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr_c, (float)beta1,
-                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_sqrt_bc2, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, coef, (float)beta1,
+                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale);
     return check_launch("adam_step");
 }
 

@@ -40,6 +40,9 @@ class FlatAdam:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._agan_grad_dst = HF.GradDst(self.grad, o, p.numel())   # backward kernels write here directly
         self.step_count = 0
+        # device-resident step counter + bias-correction coefficients (see agan_adam_step): advanced by the kernel itself, so a
+        # captured HIP graph keeps counting on replay; step_count mirrors it on the host for state_dict()
+        self.step_state = torch.zeros(4, dtype=torch.int32, device=dev)
 
     # -- torch.optim-like surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -72,7 +75,7 @@ class FlatAdam:
         self._rebind()
         self.step_count += 1
         if self.flat.is_cuda:
-            HF.adam_step_(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+            HF.adam_step_(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_state, self.lr,
                           self.betas[0], self.betas[1], self.eps, grad_scale)
         else:
             raise RuntimeError("FlatAdam.step: parameters are not on an MI355X (no CPU fallback)")
@@ -101,3 +104,6 @@ class FlatAdam:
                 self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
+        with torch.no_grad():
+            self.step_state.zero_()
+            self.step_state[0] = self.step_count

@@ -42,8 +42,13 @@ class ModelTrainer:
     def _make_noise(self, batch_size: int, z_dim: int) -> Tensor:
         return torch.randn(batch_size, z_dim, dtype=torch.float32, device=_device())
 
-    def _make_mask(self, lengths) -> Tensor:
-        """[[1]*len + [0]*(max-len)] int64 (train.py:96-100)."""
+    def _make_mask(self, lengths, maxlen: Optional[int] = None) -> Tensor:
+        """[[1]*len + [0]*(max-len)] int64 (train.py:96-100).  A device tensor of lengths is turned into the mask on the device
+        (no host sync; `maxlen` = padded caption length, the reference's max(lengths))."""
+        if isinstance(lengths, Tensor) and lengths.is_cuda:
+            if maxlen is None:
+                raise ValueError("_make_mask: maxlen is required for device-resident lengths")
+            return (torch.arange(maxlen, device=lengths.device).view(1, -1) < lengths.view(-1, 1)).to(torch.int64)
         lens = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
         mx = max(lens)
         return torch.tensor([[1] * l + [0] * (mx - l) for l in lens], dtype=torch.int64, device=_device())
@@ -148,7 +153,7 @@ class GanTrainStep(ModelTrainer):
              noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
         b = word_embs.shape[0]
         labels = self._make_match_labels(b)
-        mask = self._make_mask(lengths)
+        mask = self._make_mask(lengths, word_embs.shape[2])
         if noise is None:
             noise = self._make_noise(b, self.G.z_dim)
         fakes, _attn, mu, logvar = self.G(noise, sent_embs, word_embs, mask, eps)
@@ -220,6 +225,32 @@ class GanTrainStep(ModelTrainer):
         out["fake_imgs"] = [f.detach() for f in fakes]
         return out
 
+    # -- whole-step HIP graph ----------------------------------------------------------------------------------------
+    def capture(self, word_embs: Tensor, sent_embs: Tensor, lengths: Tensor, real_imgs: Sequence[Tensor], warmup: int = 2,
+                noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> "GraphedStep":
+        """Capture one full train step (all four optimiser updates, every stream) into a HIP graph.
+
+        The arguments become the graph's STATIC input buffers: copy each new batch into them (`.copy_()`) and call `replay()`.
+        `lengths` must be a device int64 tensor (no host reads inside the step); noise and the CA-net eps are drawn inside the
+        graph (graph-safe Philox state) unless static `noise` / `eps` buffers are given; BatchNorm counters and the Adam step
+        counters live in device memory, so replays keep advancing exactly like eager steps.  The warm-up steps are real
+        training steps.  Single-process only: with world_size > 1 run the eager `step()`."""
+        if self.g_buckets.world > 1:
+            raise RuntimeError("capture(): the all-reduce path is not captured; use step() under torch.distributed")
+        if not (isinstance(lengths, Tensor) and lengths.is_cuda and lengths.dtype == torch.int64):
+            raise ValueError("capture(): lengths must be an int64 device tensor")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream: tables, caches, allocator pools
+            for _ in range(max(1, warmup)):
+                self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
+        return GraphedStep(graph, out)
+
     # -- checkpoint / resume (SURVEY.md §8f-3: the reference only saves, and its four `Adam` objects share one Adam.pkl) --
     def state_dict(self) -> Dict:
         return {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
@@ -246,6 +277,17 @@ class GanTrainStep(ModelTrainer):
             return self._denormalise_multiple(fakes)
         finally:
             self.G.train(was_training)
+
+
+class GraphedStep:
+    """A captured train step: `replay()` runs it; `out` holds the static result tensors (losses, fake images)."""
+
+    def __init__(self, graph, out: Dict[str, Tensor]):
+        self.graph, self.out = graph, out
+
+    def replay(self) -> Dict[str, Tensor]:
+        self.graph.replay()
+        return self.out
 
 
 class DAMSMTrainStep(ModelTrainer):

@@ -195,8 +195,9 @@ int agan_reparam_bwd(const float* logvar, const float* eps, const float* dc, flo
 /* ------------------------------------------------------------------------------------------------
  * Fused Adam over one flat parameter buffer (torch.optim.Adam as configured at train.py:78-80:
  * no weight decay, no amsgrad).  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
- * ---------------------------------------------------------------------------------------------- */
-int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, double lr,
+ * step_state: 16 bytes of device memory owned by the optimiser ([0] = int32 step count, advanced by the call; [2],[3] = the
+ * bias-correction coefficients it derives) -- device-resident so that a captured HIP graph advances the step on every replay. */
+int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int32_t* step_state, double lr,
                    double beta1, double beta2, double eps, float grad_scale, void* stream);
 
 /* utility used by the host: out = sum of nsplit slabs of n floats (+bias per channel if given) */

@@ -189,3 +189,32 @@ def test_config4_stage4_extension_vs_oracle_composition():
     assert_close(p, p_ref, RTOL, "Disc512 output")
     p.sum().backward()                                                                     # backward runs through the extension
     assert all(torch.isfinite(q.grad).all() for q in G.parameters() if q.grad is not None)
+
+
+def test_hip_graph_replay_equals_eager_steps():
+    """The whole step captured as one HIP graph (all streams, four fused Adam updates with device-resident step counters):
+    warm-up + capture + replay must land where the same number of eager steps lands."""
+    def run(graphed):
+        G, Ds, enc, d = _setup(11)
+        st = TR.GanTrainStep(G, Ds, enc)
+        lens = torch.tensor(d["lens"], dtype=torch.int64, device=DEV)
+        if graphed:
+            g = st.capture(d["words"], d["sent"], lens, d["reals"], warmup=1, noise=d["noise"], eps=d["eps"])   # 1 warm-up + 1 capture run... 
+            out = None
+            for _ in range(2):
+                out = g.replay()
+        else:
+            for _ in range(3):                                  # capture itself does not execute: 1 warm-up + 2 replays = 3 steps
+                out = st.step(d["words"], d["sent"], lens, None, d["reals"], d["noise"], d["eps"])
+        torch.cuda.synchronize()
+        return st, {k: v.clone() for k, v in out.items() if k != "fake_imgs"}
+    a, oa = run(False)
+    b, ob = run(True)
+    assert int(a.g_opt.step_state[0]) == int(b.g_opt.step_state[0]) == 3
+    for k in oa:
+        assert_close(ob[k], oa[k], 1e-4, f"loss {k}")
+    for (k, va), (_, vb) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
+        assert_close(vb.double(), va.double(), 1e-4, f"G {k}")
+    for da, db in zip(a.Ds, b.Ds):
+        for (k, va), (_, vb) in zip(da.state_dict().items(), db.state_dict().items()):
+            assert_close(vb.double(), va.double(), 1e-4, f"D {k}")

@@ -356,10 +356,12 @@ def test_fused_adam_vs_oracle():
     p = torch.randn(n, generator=gen)
     m, v = torch.zeros(n), torch.zeros(n)
     pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)          # device-resident step counter (advanced by the kernel)
     for step in range(1, 4):
         gr = torch.randn(n, generator=gen) * 0.1
         O.adam_update(p, gr, m, v, step, 2e-4, 0.5, 0.999, 1e-8)
-        HF.adam_step_(pd, gr.to(DEV), md, vd, step, 2e-4, 0.5, 0.999, 1e-8)
+        HF.adam_step_(pd, gr.to(DEV), md, vd, state, 2e-4, 0.5, 0.999, 1e-8)
+    assert int(state[0]) == 3
     assert_close(pd, p, 1e-6, "param")
     assert_close(md, m, 1e-6, "exp_avg")
     assert_close(vd, v, 1e-5, "exp_avg_sq")
