@@ -19,20 +19,27 @@ using namespace agan::conv;
 
 namespace {
 
+// table layout: n entries {element offset incl. tap, packed (dy,dx)} for the weight-gradient kernels, followed by n entries
+// {channel byte offset ci*IH*IW*4, byte offset of tap row t in the per-workgroup LDS tap table} for the gather kernels
 __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int n, int K, int RS, int S, int IHW, int IW, int DY) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    int2 e;
+    int2 a, b;
     if (k < K) {
         const int c = k / RS, rs = k - c * RS, r = rs / S, q = rs - r * S;
         const int dy = r * DY, dx = q * DY;
-        e.x = c * IHW + dy * IW + dx;
-        e.y = (dy & 0xFFFF) | (dx << 16);
+        a.x = c * IHW + dy * IW + dx;
+        a.y = (dy & 0xFFFF) | (dx << 16);
+        b.x = c * IHW * 4;
+        b.y = rs * kTapRowBytes;
     } else {
-        e.x = 0;
-        e.y = kSentinelDy & 0xFFFF;
+        a.x = 0;
+        a.y = kSentinelDy & 0xFFFF;
+        b.x = 0;
+        b.y = RS * kTapRowBytes;          // the all-out-of-range row of the tap table
     }
-    tab[k] = e;
+    tab[k] = a;
+    tab[n + k] = b;
 }
 
 // ================================================================================================
@@ -60,6 +67,10 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
 
     __shared__ float As[2][BK][BM];
     __shared__ float Bs[2][BK][BN];
+    // per-pixel byte offset of every tap (padding test folded in as an out-of-range offset), row RS = "always out of range":
+    // computed once per workgroup, so the K loop does no address arithmetic beyond one LDS read per gathered element
+    __shared__ unsigned Toff[kMaxTaps + 1][BM];
+    static_assert(BM * 4 == kTapRowBytes, "tap table row size");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,16 +90,26 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
     const int akg = __builtin_amdgcn_readfirstlane(tid / BM);
     const int m = m0 + am;
     const bool mvalid = m < g.Mtot;
-    int iy0, ix0, pix0;   // pix0: element offset of (b, c=0, iy0, ix0) -- may point outside the image, used only when valid
     {
         const int mm = mvalid ? m : 0;
         const int b = g.dHWs.div(mm), rem = mm - b * g.HWs;
         const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
-        iy0 = yq * g.SY + (py ? g.OY1 : g.OY0);
-        ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
-        pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
-        if (!mvalid) iy0 = -(1 << 20);      // every tap of a padding row fails the range check
+        const int iy0 = yq * g.SY + (py ? g.OY1 : g.OY0), ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
+        const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
+        int r = 0, q = akg;                       // this thread fills taps akg, akg + NG, ... (q may start beyond S: normalise)
+        while (q >= g.S) { q -= g.S; ++r; }
+        for (int t = akg; t < g.RS; t += NG) {
+            const int dy = r * g.DY, dx = q * g.DY;
+            const bool ok = mvalid & ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
+            Toff[t][am] = ok ? (unsigned)(pix0 + dy * g.IW + dx) * 4u : kOOB;
+            q += NG;
+            while (q >= g.S) { q -= g.S; ++r; }
+        }
+        if (akg == 0) Toff[g.RS][am] = kOOB;
     }
+    __syncthreads();
+    const char* toff_lane = reinterpret_cast<const char*>(&Toff[0][am]);
+    const int2* ktb = ktab + ktable_entries(g.K);        // second half of the table: {channel byte offset, tap row byte offset}
     // B tile mapping
     int bkr[BV], bnc[BV];
 #pragma unroll
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
         constexpr int P = decltype(set)::value;
         const int kb = kbeg + kt * BK;
         // this wave's AK table entries in one wide scalar load (wave-uniform address, 16-byte aligned)
-        const int4* tk4 = reinterpret_cast<const int4*>(ktab + kb + akg * AK);
+        const int4* tk4 = reinterpret_cast<const int4*>(ktb + kb + akg * AK);
         int te[2 * AK];
 #pragma unroll
         for (int i = 0; i < AK / 2; ++i) {
@@ -116,11 +137,8 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
         }
 #pragma unroll
         for (int i = 0; i < AK; ++i) {
-            const int ex = te[2 * i], ey = te[2 * i + 1];
-            const int dy = (int)(short)(ey & 0xFFFF), dx = ey >> 16;
-            const bool ok = ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
-            const unsigned off = (unsigned)(pix0 + ex) * 4u;
-            areg[P][i] = buf_load(rin, ok ? off : kOOB);
+            const unsigned voff = *reinterpret_cast<const unsigned*>(toff_lane + te[2 * i + 1]);
+            areg[P][i] = buf_load_s(rin, voff, (unsigned)te[2 * i]);
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
@@ -319,41 +337,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    // Per pixel tile, the byte offset of every (pixel, tap) -- padding and the pixel tail folded in as kWOOB -- and of the
+    // pixel's dY element are computed ONCE by the workgroup into a small LDS table, two tiles ahead of the loads that use them;
+    // a staged element then costs one LDS read and one add instead of a division-free but still ~10-instruction address chain.
+    __shared__ unsigned Toff[2][kMaxTaps + 1][BP];
+    __shared__ unsigned Doff[2][BP];
     // the reduction rows this thread stages never change across the pixel loop: fetch their table entries once
-    int tex[XR], tey[XR];
+    // (second table half: {channel byte offset, tap row * 512}); rows past K read the all-out-of-range tap row
+    unsigned xcoff[XR];
+    int xtrow[XR];
 #pragma unroll
     for (int ii = 0; ii < XR; ++ii) {
-        const int2 e = ktab[i0 + wave * (BI / 4) + 2 * ii + half];
-        tex[ii] = e.x;
-        tey[ii] = e.y;
+        const int2 e = ktab[ktable_entries(g.K) + i0 + wave * (BI / 4) + 2 * ii + half];
+        xcoff[ii] = (unsigned)e.x;
+        xtrow[ii] = (e.y / kTapRowBytes) * BP + pl;        // word index into Toff[buf]
     }
-    const int nb = j0 + wave * (BJ / 4) + half;
-
-    float xreg[2][XR], yreg[2][YR];     // two pixel tiles in flight (see the gather kernel)
-
-    auto load_tile = [&](auto set, int pt) {
-        constexpr int P = decltype(set)::value;
+    unsigned ynoff[YR];
+#pragma unroll
+    for (int jj = 0; jj < YR; ++jj)       // output channels past Cout only feed accumulator rows the epilogue never stores: clamp
+        ynoff[jj] = (unsigned)(min(j0 + wave * (BJ / 4) + half + 2 * jj, g.Cout - 1) * ohw) * 4u;
+    // table fill: thread -> pixel tid & 31, taps tid >> 5 and (tid >> 5) + 8
+    const int ft0 = tid >> 5, ft1 = ft0 + 8;
+    int fdy0, fdx0, fdy1, fdx1;
+    {
+        const int r0 = ft0 / g.S, r1 = ft1 / g.S;
+        fdy0 = r0 * g.DY; fdx0 = (ft0 - r0 * g.S) * g.DY;
+        fdy1 = r1 * g.DY; fdx1 = (ft1 - r1 * g.S) * g.DY;
+    }
+    auto fill_offsets = [&](int pt) {
+        const int b2 = pt & 1;
         const int p = pbeg + pt * BP + pl;
         const bool pvalid = p < pend;
         const int pp = pvalid ? p : 0;
         const int b = g.dHWs.div(pp), rem = pp - b * g.HWs;
         const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
-        const int iy0 = pvalid ? yq * g.SY + (py ? g.OY1 : g.OY0) : -(1 << 20);
-        const int ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
+        const int iy0 = yq * g.SY + (py ? g.OY1 : g.OY0), ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
         const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
-        const int dyoff = b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px);
-#pragma unroll
-        for (int ii = 0; ii < XR; ++ii) {
-            const int ddy = (int)(short)(tey[ii] & 0xFFFF), ddx = tey[ii] >> 16;
-            const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
-            const unsigned off = (unsigned)(pix0 + tex[ii]) * 4u;
-            xreg[P][ii] = buf_load(rx, ok ? off : kOOB);
+        if (ft0 < g.RS) {
+            const bool ok = pvalid & ((unsigned)(iy0 + fdy0) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx0) < (unsigned)g.IW);
+            Toff[b2][ft0][pl] = ok ? (unsigned)(pix0 + fdy0 * g.IW + fdx0) * 4u : kWOOB;
         }
-#pragma unroll
-        for (int jj = 0; jj < YR; ++jj) {
-            const int n = nb + 2 * jj;
-            yreg[P][jj] = buf_load(rdy, (pvalid & (n < g.Cout)) ? (unsigned)(dyoff + n * ohw) * 4u : kOOB);
+        if (ft1 < g.RS) {
+            const bool ok = pvalid & ((unsigned)(iy0 + fdy1) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx1) < (unsigned)g.IW);
+            Toff[b2][ft1][pl] = ok ? (unsigned)(pix0 + fdy1 * g.IW + fdx1) * 4u : kWOOB;
         }
+        if (ft0 == 0) Doff[b2][pl] = pvalid ? (unsigned)(b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kWOOB;
+    };
+    if (tid < 2 * BP) Toff[tid >> 5][g.RS][pl] = kWOOB;
+
+    float xreg[2][XR], yreg[2][YR];     // two pixel tiles in flight (see the gather kernel)
+
+    auto load_tile = [&](auto set, int pt) {
+        constexpr int P = decltype(set)::value;
+        const unsigned* to = &Toff[pt & 1][0][0];
+        const unsigned doff = Doff[pt & 1][pl];
+#pragma unroll
+        for (int ii = 0; ii < XR; ++ii) xreg[P][ii] = buf_load(rx, to[xtrow[ii]] + xcoff[ii]);
+#pragma unroll
+        for (int jj = 0; jj < YR; ++jj) yreg[P][jj] = buf_load(rdy, doff + ynoff[jj]);
     };
     auto store_tile = [&](auto set, int buf) {
         constexpr int P = decltype(set)::value;
@@ -376,6 +417,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
     auto step = [&](auto full, auto cur, auto nxt, int pt, int buf) {
         constexpr bool FULL = decltype(full)::value;
         if (FULL || pt + 2 < npt) load_tile(cur, pt + 2);
+        fill_offsets(pt + 3);           // past the last tile every entry is kWOOB: harmless, so never conditional
         float av[2][TI], bv[2][TJ];
 #pragma unroll
         for (int t = 0; t < TI; ++t) av[0][t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][half];
@@ -400,8 +442,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         __syncthreads();
     };
 
+    fill_offsets(0);
+    fill_offsets(1);
+    __syncthreads();
     if (npt > 0) load_tile(S0{}, 0);
     if (npt > 1) load_tile(S1{}, 1);
+    __syncthreads();
+    fill_offsets(2);
     if (npt > 0) store_tile(S0{}, 0);
     __syncthreads();
     int pt = 0;
@@ -589,7 +636,7 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
 
 size_t agan_conv_ktable_elems(const agan_conv_geom* g) {
     if (check_geom(g)) return 0;
-    return (size_t)ktable_entries(g->Cin * g->R * g->S) * 2;
+    return (size_t)ktable_entries(g->Cin * g->R * g->S) * 4;      // two int2 halves (see ktable_kernel)
 }
 
 int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
@@ -652,6 +699,8 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
     const bool up = pack_mode == AGAN_PACK_UP_FWD;
+    AGAN_REQUIRE(1LL * g.B * g.Cin * g.IH * g.IW < (1LL << 29) && 1LL * g.B * g.Cout * g.OH * g.OW < (1LL << 29),
+                 "conv_wgrad: tensor exceeds 2^29 elements");
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
     hipStream_t st = as_stream(stream);

@@ -36,6 +36,11 @@ struct Geom {
 // Entries >= K are sentinels whose dy fails every range check.
 constexpr int kTabPad = 128;
 constexpr int kSentinelDy = -32768;
+constexpr int kMaxTaps = 16;           // taps per class the gather kernels' LDS tap table holds (RS <= 16: up to 4x4)
+constexpr int kTapRowBytes = 128 * 4;  // one tap row = 128 pixels of a workgroup tile
+// weight-gradient kernels add a per-lane channel offset to the tabulated tap offset, so their out-of-range marker must
+// survive that add without wrapping: tensors on that path stay below 2^31 bytes (checked on the host)
+constexpr unsigned kWOOB = 0x80000000u;
 __host__ __device__ inline int ktable_entries(int K) { return (K + kTabPad - 1) / kTabPad * kTabPad + kTabPad; }
 
 inline Geom make_geom(const agan_conv_geom* g) {
@@ -52,7 +57,7 @@ inline int check_geom(const agan_conv_geom* g) {
     AGAN_REQUIRE(g != nullptr, "conv: null geometry");
     AGAN_REQUIRE(g->B > 0 && g->Cin > 0 && g->IH > 0 && g->IW > 0 && g->Cout > 0 && g->OH > 0 && g->OW > 0,
                  "conv: non-positive dimension");
-    AGAN_REQUIRE(g->R > 0 && g->S > 0 && g->R <= 8 && g->S <= 8, "conv: taps %dx%d unsupported", g->R, g->S);
+    AGAN_REQUIRE(g->R > 0 && g->S > 0 && g->R * g->S <= 16, "conv: taps %dx%d unsupported", g->R, g->S);
     AGAN_REQUIRE(g->OS == 1 || g->OS == 2, "conv: OS must be 1 or 2");
     AGAN_REQUIRE(g->OH % g->OS == 0 && g->OW % g->OS == 0, "conv: OH/OW not divisible by OS");
     const long long in_elems = 1LL * g->B * g->Cin * g->IH * g->IW, out_elems = 1LL * g->B * g->Cout * g->OH * g->OW;
@@ -70,6 +75,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_
 }
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {   // + wave-uniform byte offset
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));

@@ -11,10 +11,6 @@ using namespace agan::conv;
 
 namespace {
 
-__device__ __forceinline__ float buf_load_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
 // forward / dgrad, Cout <= 4.  RS = taps per class (1, 4, 9, 16), S = tap columns.
 template <int RS, int S>
 __global__ __launch_bounds__(256) void conv_small_n_kernel(const float* __restrict__ in, const float* __restrict__ wk,

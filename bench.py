@@ -49,7 +49,7 @@ class ConvTimer:
     kernels are enqueued on); durations are read after the timed region has been synchronised."""
 
     def __init__(self, mode="f32"):
-        self.records, self.enabled, self._open, self.mode = [], False, None, mode
+        self.records, self.keys, self.enabled, self._open, self.mode = [], [], False, None, mode
 
     def begin(self, kind, phase, g):
         if not self.enabled:
@@ -65,6 +65,7 @@ class ConvTimer:
         nbytes = 4.0 * (g.B * g.Cin * g.IH * g.IW + g.B * g.Cout * g.OH * g.OW + g.Cout * K * (g.OS * g.OS))
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
+        self._key = f"{phase:5s} {kind:4s} B{g.B} {g.Cin:4d}x{g.IH:<3d} -> {g.Cout:4d}x{g.OH:<3d} taps {g.R}x{g.S} cls {g.OS * g.OS}"
         self._open = (name, algorithmic, executed, nbytes, e0)
 
     def end(self):
@@ -73,7 +74,21 @@ class ConvTimer:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.records.append(self._open + (e1,))
+        self.keys.append(self._key)
         self._open = None
+
+    def layer_table(self, steps):
+        """per (phase, layer shape): launches and ms per step, executed TFLOP/s -- the list the next optimisation is read from"""
+        by = {}
+        for key, (name, fa, fe, nb, e0, e1) in zip(self.keys, self.records):
+            d = by.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fe
+        rows = sorted(by.items(), key=lambda kv: -kv[1][1])
+        out = [f"{'phase kind shape':58s} {'n/step':>6s} {'ms/step':>8s} {'exec TF/s':>9s}"]
+        for key, (n, ms, fe) in rows:
+            out.append(f"{key:58s} {n / steps:6.1f} {ms / steps:8.3f} {fe / (ms * 1e-3) / 1e12:9.1f}")
+        out.append(f"{'total':58s} {sum(v[0] for v in by.values()) / steps:6.1f} {sum(v[1] for v in by.values()) / steps:8.3f}")
+        return "\n".join(out)
 
     def summary(self):
         by = {}
@@ -156,6 +171,7 @@ def main():
                     help="replay the whole step as one captured HIP graph (auto: on for 1 GPU, off under torch.distributed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented steps to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +233,7 @@ def main():
     overlap = step.overlap_discriminators
     step.overlap_discriminators = False
     timer.records.clear()
+    timer.keys.clear()
     timer.enabled = True
     for _ in range(ROOF_STEPS):
         step.step(words, sent, lens_dev if use_graph else lens, None, reals)
@@ -225,6 +242,9 @@ def main():
     step.overlap_discriminators = overlap
     roofline_timing = (f"HIP events (on the launch stream) around every conv-engine launch in {ROOF_STEPS} single-stream eager steps run "
                        "right after the timed region; the timed region itself overlaps streams / replays a HIP graph")
+    if rank == 0 and args.layer_table:
+        with open(args.layer_table, "w") as f:
+            f.write(timer.layer_table(ROOF_STEPS) + "\n")
     if rank == 0:
         summ = timer.summary()
         dom = max(summ.items(), key=lambda kv: kv[1][1]) if summ else None
