@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         ynoff[jj] = (unsigned)(min(j0 + wave * (BJ / 4) + half + 2 * jj, g.Cout - 1) * ohw) * 4u;
     // table fill: thread -> pixel tid & 31, taps tid >> 5 and (tid >> 5) + 8
     const int ft0 = tid >> 5, ft1 = ft0 + 8;
+    const int frow0 = min(ft0, g.RS), frow1 = min(ft1, g.RS);
     int fdy0, fdx0, fdy1, fdx1;
     {
         const int r0 = ft0 / g.S, r1 = ft1 / g.S;
@@ -373,15 +374,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         const int yq = g.dOWs.div(rem), xq = rem - yq * g.OWs;
         const int iy0 = yq * g.SY + (py ? g.OY1 : g.OY0), ix0 = xq * g.SY + (px ? g.OY1 : g.OY0);
         const int pix0 = b * g.Cin * ihw + iy0 * g.IW + ix0;
-        if (ft0 < g.RS) {
-            const bool ok = pvalid & ((unsigned)(iy0 + fdy0) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx0) < (unsigned)g.IW);
-            Toff[b2][ft0][pl] = ok ? (unsigned)(pix0 + fdy0 * g.IW + fdx0) * 4u : kWOOB;
-        }
-        if (ft1 < g.RS) {
-            const bool ok = pvalid & ((unsigned)(iy0 + fdy1) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx1) < (unsigned)g.IW);
-            Toff[b2][ft1][pl] = ok ? (unsigned)(pix0 + fdy1 * g.IW + fdx1) * 4u : kWOOB;
-        }
-        if (ft0 == 0) Doff[b2][pl] = pvalid ? (unsigned)(b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kWOOB;
+        // branch-free (the step stays one basic block for the scheduler): a tap index past RS writes kWOOB into the spare row RS,
+        // and all eight tap groups store the same dY offset
+        const bool ok0 = pvalid & (ft0 < g.RS) & ((unsigned)(iy0 + fdy0) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx0) < (unsigned)g.IW);
+        const bool ok1 = pvalid & (ft1 < g.RS) & ((unsigned)(iy0 + fdy1) < (unsigned)g.IH) & ((unsigned)(ix0 + fdx1) < (unsigned)g.IW);
+        Toff[b2][frow0][pl] = ok0 ? (unsigned)(pix0 + fdy0 * g.IW + fdx0) * 4u : kWOOB;
+        Toff[b2][frow1][pl] = ok1 ? (unsigned)(pix0 + fdy1 * g.IW + fdx1) * 4u : kWOOB;
+        // (or-ing the marker in keeps this a select of constants: a value select makes the compiler branch around the multiplies,
+        // and a second basic block in the loop costs exact wait counts)
+        Doff[b2][pl] = ((unsigned)(b * g.Cout * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u) | (pvalid ? 0u : kWOOB);
     };
     if (tid < 2 * BP) Toff[tid >> 5][g.RS][pl] = kWOOB;
 
@@ -414,9 +415,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // One pixel tile.  The staging work of the step -- gathers of tile pt+2 into the free register set, LDS stores of tile pt+1
+    // from the other set -- is spread over the 16 MFMA k-steps instead of sitting in front of / behind them: with two waves per
+    // SIMD there is not enough parallelism to hide a serial address+load prologue behind the other wave's MFMAs.
     auto step = [&](auto full, auto cur, auto nxt, int pt, int buf) {
         constexpr bool FULL = decltype(full)::value;
-        if (FULL || pt + 2 < npt) load_tile(cur, pt + 2);
+        constexpr int PC = decltype(cur)::value, PN = decltype(nxt)::value;
+        constexpr int NS = BP / 2, L = XR + YR;
+        const bool do_load = FULL || pt + 2 < npt, do_store = FULL || pt + 1 < npt;
+        unsigned xo[XR];
+        const unsigned* to = &Toff[pt & 1][0][0];            // table of tile pt+2 (same parity)
+#pragma unroll
+        for (int ii = 0; ii < XR; ++ii) xo[ii] = to[xtrow[ii]] + xcoff[ii];
+        const unsigned doff = Doff[pt & 1][pl];
         fill_offsets(pt + 3);           // past the last tile every entry is kWOOB: harmless, so never conditional
         float av[2][TI], bv[2][TJ];
 #pragma unroll
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
         for (int t = 0; t < TJ; ++t) bv[0][t] = Ys[buf][wj * (BJ / 2) + t * 32 + pl][half];
 #pragma unroll
         for (int pp = 0; pp < BP; pp += 2) {
-            const int c = (pp >> 1) & 1;
+            const int c = (pp >> 1) & 1, q = pp >> 1;
             if (pp + 2 < BP) {
 #pragma unroll
                 for (int t = 0; t < TI; ++t) av[c ^ 1][t] = Xs[buf][wi * (BI / 2) + t * 32 + pl][pp + 2 + half];
@@ -437,8 +448,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 #pragma unroll
                 for (int b = 0; b < TI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][a], av[c][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int it = q * L / NS; it < (q + 1) * L / NS; ++it) {
+                if (it < XR) {
+                    if (do_store) Xs[buf ^ 1][wave * (BI / 4) + 2 * it + half][pl] = xreg[PN][it];
+                    if (do_load) xreg[PC][it] = buf_load(rx, xo[it]);
+                } else {
+                    const int jj = it - XR;
+                    if (do_store) Ys[buf ^ 1][wave * (BJ / 4) + 2 * jj + half][pl] = yreg[PN][jj];
+                    if (do_load) yreg[PC][jj] = buf_load(rdy, doff + ynoff[jj]);
+                }
+            }
         }
-        if (FULL || pt + 1 < npt) store_tile(nxt, buf ^ 1);
         __syncthreads();
     };
 

@@ -185,7 +185,8 @@ struct WgradPlan {
 
 inline WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     WgradPlan p;
-    p.bi = g.K >= 96 ? 128 : 64;
+    // 128-row tiles unless the 64-row tiling pads K less (K = 576 for the 64-channel 3x3 layers: 9 x 64 instead of 5 x 128)
+    p.bi = (g.K >= 96 && cdiv(g.K, 128) * 128 <= cdiv(g.K, 64) * 64) ? 128 : 64;
     p.bj = g.Cout >= 96 ? 128 : 64;
     p.itiles = cdiv(g.K, p.bi);
     p.jtiles = cdiv(g.Cout, p.bj);
