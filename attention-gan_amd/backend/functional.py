@@ -9,7 +9,9 @@ from __future__ import annotations
 import ctypes
 import math
 from ctypes import byref, c_void_p
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
+
+import contextlib
 
 import torch
 from torch import Tensor
@@ -196,6 +198,61 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
         obs.end()
 
 
+# Weight gradients feed nothing but the optimiser, so a training step may fork them onto a side stream: they then overlap the
+# HBM-bound kernels (BatchNorm / activation backward, slab sums) of the data-gradient chain instead of queueing between them.
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE_DIRTY: Dict[int, bool] = {}
+_WGRAD_SIDE = [False]
+
+
+def set_wgrad_side_stream(flag: bool) -> bool:
+    """Fork weight/bias gradients that go straight into a flat gradient buffer (grad_dst) onto a per-stream side stream.
+    Whoever reads those gradients must call join_side_stream() on the forking stream first (FlatAdam.step and GradBuckets do)."""
+    old = _WGRAD_SIDE[0]
+    _WGRAD_SIDE[0] = bool(flag)
+    return old
+
+
+def wgrad_side_stream_enabled() -> bool:
+    return _WGRAD_SIDE[0]
+
+
+def join_all_side_streams(target) -> None:
+    """Make `target` (a stream about to read gradients, e.g. the collective stream) wait for every forked side stream."""
+    for key, side in _SIDE_STREAMS.items():
+        if _SIDE_DIRTY.get(key):
+            target.wait_stream(side)
+
+
+def set_side_stream_for(stream, side) -> None:
+    """Use `side` for the weight gradients forked off `stream` (instead of a private one).  The train step maps each
+    discriminator stream to the stream it was itself forked from: that stream idles during the discriminator updates, and a
+    fork of a fork does not survive hipStreamEndCapture on ROCm 7.2."""
+    _SIDE_STREAMS[stream.cuda_stream] = side
+
+
+def _fork_side_stream():
+    cur = torch.cuda.current_stream()
+    key = cur.cuda_stream
+    side = _SIDE_STREAMS.get(key)
+    if side is None:
+        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    _SIDE_DIRTY[key] = True
+    return side
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for the weight-gradient work forked from it (no-op if there is none)."""
+    if not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    key = cur.cuda_stream
+    if _SIDE_DIRTY.get(key):
+        cur.wait_stream(_SIDE_STREAMS[key])
+        _SIDE_DIRTY[key] = False
+
+
 class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst):
@@ -222,25 +279,33 @@ class _ConvFn(Function):
         Cout, _, kh, kw = w.shape
         gf, pf, gd, pd, _ = conv_geoms(ctx.kind, B, Cin, H, W, Cout, kh)
         dx = dw = db = None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        side = None
+        if _WGRAD_SIDE[0] and want_w and ctx.wdst is not None and (not want_b or ctx.bdst is not None):
+            kt = ktable(gf, x.device)                  # (tables are built on the forking stream)
+            side = _fork_side_stream()                 # dy is ready on the current stream at this point
+            x.record_stream(side)
+            dy.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if want_w:
+                dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, x)
+                lib = L.load()
+                nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
+                ws, wsp = _ws(nbytes, x)
+                kt = ktable(gf, x.device)
+                obs = _OBSERVER[0]
+                if obs is not None:
+                    obs.begin(ctx.kind, "wgrad", gf)
+                L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wacc, wsp, nbytes,
+                       _stream())
+                if obs is not None:
+                    obs.end()
+            if want_b:
+                dbbuf, bacc, db = _grad_out(ctx.bdst, (Cout,), x)
+                L.call("agan_bias_grad", _p(dy), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
-        if ctx.needs_input_grad[1]:
-            dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, x)
-            lib = L.load()
-            nbytes = lib.agan_conv_wgrad_ws_bytes(byref(gf))
-            ws, wsp = _ws(nbytes, x)
-            kt = ktable(gf, x.device)
-            obs = _OBSERVER[0]
-            if obs is not None:
-                obs.begin(ctx.kind, "wgrad", gf)
-            L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wacc, wsp, nbytes,
-                   _stream())
-            if obs is not None:
-                obs.end()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbbuf, bacc, db = _grad_out(ctx.bdst, (Cout,), x)
-            L.call("agan_bias_grad", _p(dy), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
         return dx, dw, db, None, None, None, None
 
 

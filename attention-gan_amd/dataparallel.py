@@ -15,6 +15,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from .backend import functional as HF
 from .optim import FlatAdam
 
 
@@ -81,6 +82,7 @@ class GradBuckets:
         chunk = self.opt.grad[s:e]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            HF.join_all_side_streams(self.comm_stream)          # weight gradients forked onto side streams
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

@@ -66,12 +66,16 @@ class FlatAdam:
                 continue
             view = self.grad[o:o + p.numel()].view(p.shape)
             if g is not None:
+                if p._agan_grad_dst.written and HF.wgrad_side_stream_enabled():
+                    # the kernel wrote the slice on a side stream; a clone made by autograd on the main stream read it too early
+                    raise RuntimeError("FlatAdam: autograd cloned a gradient that was written on the weight-gradient side stream")
                 view.copy_(g)
                 copies += 1
             p.grad = view
         return copies
 
     def step(self, grad_scale: float = 1.0) -> None:
+        HF.join_side_stream()          # weight gradients forked off the current stream (functional.set_wgrad_side_stream)
         self._rebind()
         self.step_count += 1
         if self.flat.is_cuda:

@@ -12,6 +12,7 @@ import torch
 from torch import Tensor
 from torch.nn import Module
 
+from ..backend import functional as HF
 from ..dataparallel import GradBuckets, broadcast_module_, world_size
 from ..losses.disc_loss import NonSaturatingDiscLoss
 from ..losses.gen_loss import NonSaturatingGenLoss
@@ -142,6 +143,10 @@ class GanTrainStep(ModelTrainer):
         self.d_losses: List = []
         self.damsm_losses: List = []
         self.overlap_discriminators = True
+        # optional: weight gradients on a side stream per compute stream (functional.set_wgrad_side_stream), joined by every
+        # optimiser step.  Measured on MI355X at the metric config: 763 vs 778 images/s with it on -- the step is a sum of
+        # kernels that each fill the chip, so the extra concurrency only adds cache pressure.  Off by default.
+        self.overlap_weight_gradients = False
         self._streams: List = []
 
     def _d_streams(self, n: int, device) -> List:
@@ -151,6 +156,13 @@ class GanTrainStep(ModelTrainer):
 
     def step(self, word_embs: Tensor, sent_embs: Tensor, lengths, class_ids, real_imgs: Sequence[Tensor],
              noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        prev_side = HF.set_wgrad_side_stream(self.overlap_weight_gradients and word_embs.is_cuda)
+        try:
+            return self._step(word_embs, sent_embs, lengths, class_ids, real_imgs, noise, eps)
+        finally:
+            HF.set_wgrad_side_stream(prev_side)
+
+    def _step(self, word_embs, sent_embs, lengths, class_ids, real_imgs, noise, eps) -> Dict[str, Tensor]:
         b = word_embs.shape[0]
         labels = self._make_match_labels(b)
         mask = self._make_mask(lengths, word_embs.shape[2])
@@ -164,6 +176,9 @@ class GanTrainStep(ModelTrainer):
         # Autograd replays each backward on the stream its forward ran on.
         main = torch.cuda.current_stream() if fakes[0].is_cuda else None
         streams = self._d_streams(len(self.Ds), fakes[0].device) if (main is not None and self.overlap_discriminators) else None
+        if streams is not None:
+            for st in streams:                      # discriminator weight gradients run on the (otherwise idle) main stream
+                HF.set_side_stream_for(st, main)
         for i, (d, opt, bk) in enumerate(zip(self.Ds, self.d_opts, self.d_buckets)):
             if streams is not None:
                 streams[i].wait_stream(main)

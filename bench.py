@@ -119,7 +119,9 @@ def build(dev, batch, HF, encoder="standin"):
     enc = (ENC.StandInImageEncoder(EMB) if encoder == "standin" else ENC.CNNEncoder(EMB)).to(dev)
     enc.freeze_all_weights()
     enc.eval()                     # the reference loads it with _load_weights(), which puts it in eval mode (trainer.py:124)
-    return TR.GanTrainStep(G, Ds, enc)
+    step = TR.GanTrainStep(G, Ds, enc)
+    step.overlap_weight_gradients = os.environ.get("AGAN_WGRAD_SIDE_STREAM", "0") == "1"      # (A/B switch)
+    return step
 
 
 def synthetic_batch(dev, batch, seed):
@@ -230,8 +232,8 @@ def main():
     # event-to-event time there includes whatever runs beside it.  The same launches (same shapes, same kernels, same inputs) are
     # therefore timed in ROOF_STEPS instrumented eager steps on one stream, right after the timed region, in this process.
     ROOF_STEPS = 2
-    overlap = step.overlap_discriminators
-    step.overlap_discriminators = False
+    overlap = step.overlap_discriminators, step.overlap_weight_gradients
+    step.overlap_discriminators = step.overlap_weight_gradients = False
     timer.records.clear()
     timer.keys.clear()
     timer.enabled = True
@@ -239,7 +241,7 @@ def main():
         step.step(words, sent, lens_dev if use_graph else lens, None, reals)
     torch.cuda.synchronize()
     timer.enabled = False
-    step.overlap_discriminators = overlap
+    step.overlap_discriminators, step.overlap_weight_gradients = overlap
     roofline_timing = (f"HIP events (on the launch stream) around every conv-engine launch in {ROOF_STEPS} single-stream eager steps run "
                        "right after the timed region; the timed region itself overlaps streams / replays a HIP graph")
     if rank == 0 and args.layer_table:
