@@ -41,6 +41,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave-wide sums of N per-lane values r[0..N) (N a power of two <= 64) by a transposing butterfly: each exchange halves the
+// values a lane still carries, so the whole reduction costs N-1 + log2(64/N) shuffles instead of 6*N.  Returns the full sum of
+// element `idx` (set per lane; the 64/N lanes that share an idx all hold the same sum).  r[] is clobbered.
+template <int N>
+__device__ __forceinline__ float wave_sum_scatter(float (&r)[N], int lane, int& idx) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
+    idx = 0;
+    int width = 32;
+#pragma unroll
+    for (int n = N / 2; n >= 1; n >>= 1, width >>= 1) {
+        const bool up = (lane & width) != 0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const float send = up ? r[j] : r[j + n];
+            const float keep = up ? r[j + n] : r[j];
+            r[j] = keep + __shfl_xor(send, width, 64);
+        }
+        if (up) idx += n;
+    }
+    float v = r[0];
+#pragma unroll
+    for (int w = 64 / N / 2; w >= 1; w >>= 1) v += __shfl_xor(v, w, 64);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

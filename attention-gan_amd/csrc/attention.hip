@@ -127,11 +127,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
         if (live) di[(size_t)c * HW] = s;
+        float part[TMAX];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            const float r = wave_sum(dv * a[t] + iv * ds[t]);
-            if (lane == 0 && t < T) atomicAdd(&acc[c][t], r);
-        }
+        for (int t = 0; t < TMAX; ++t) part[t] = dv * a[t] + iv * ds[t];
+        int t_own;
+        const float r = wave_sum_scatter<TMAX>(part, lane, t_own);       // TMAX + 1 shuffles per channel, not 6 * TMAX
+        if ((lane & (64 / TMAX - 1)) == 0 && t_own < T) atomicAdd(&acc[c][t_own], r);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * T; i += 256) {

@@ -17,11 +17,14 @@ constexpr int kNT = 320;      // threads per pair workgroup (5 waves): >= S and 
 constexpr int kMaxB = 128;
 
 // Everything the forward of one (image j, caption i) pair produces, left in LDS / registers for the caller.
-template <int TMAX>
+// DR = rows of the channel-indexed matrices (>= D).  The <12, 256> instance (seq_len <= 12, nef <= 256: the metric config) is
+// 43 KB, so three pair workgroups share a CU and the B*B = 576 pairs of batch 24 run in ONE round of 768 slots; the 65 KB
+// <16, 320> instance fits two per CU = 512 slots, i.e. a second round for the last 64 pairs.
+template <int TMAX, int DR = kNT>
 struct PairSmem {
-    float e[kNT][TMAX + 1];    // caption words   e[d][w]  (0 for w >= L)
+    float e[DR][TMAX + 1];     // caption words   e[d][w]  (0 for w >= L)
     float a2[kNT][TMAX + 1];   // attention       a2[r][w] (softmax over regions of gamma1 * softmax over words)
-    float c[kNT][TMAX + 1];    // weighted context c[d][w]
+    float c[DR][TMAX + 1];     // weighted context c[d][w]
     float num[TMAX], n1[TMAX], n2[TMAX], cosv[TMAX];
     float colmax[TMAX], colsum[TMAX];
     float red[8];
@@ -29,8 +32,8 @@ struct PairSmem {
 
 // Forward of a pair.  On return (after the trailing barrier): sm.e, sm.a2, sm.c, sm.cosv/num/n1/n2 are valid;
 // a1[] holds thread r's first-softmax row (valid for r < S).
-template <int TMAX>
-__device__ __forceinline__ void pair_forward(PairSmem<TMAX>& sm, const float* __restrict__ fj, const float* __restrict__ ei,
+template <int TMAX, int DR>
+__device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float* __restrict__ fj, const float* __restrict__ ei,
                                              int D, int T, int S, int L, float scale, float gamma1, float eps, float (&a1)[TMAX]) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -119,16 +122,16 @@ __device__ __forceinline__ void pair_forward(PairSmem<TMAX>& sm, const float* __
     __syncthreads();
 }
 
-template <int TMAX>
+template <int TMAX, int DR>
 __global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
                                                              const int64_t* __restrict__ lens, float gamma1, float gamma2, float gamma3,
                                                              float* __restrict__ sim, float* __restrict__ maps, int B, int D, int T, int S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    PairSmem<TMAX, DR>& sm = *reinterpret_cast<PairSmem<TMAX, DR>*>(smem_raw);
     const int j = blockIdx.x, i = blockIdx.y;      // image j, caption i
     const int L = min((int)lens[i], T);
     float a1[TMAX];
-    pair_forward<TMAX>(sm, feat + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L, rsqrtf((float)D), gamma1, 1e-8f, a1);
+    pair_forward<TMAX, DR>(sm, feat + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L, rsqrtf((float)D), gamma1, 1e-8f, a1);
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w]);     // words_loss.py:77-79
@@ -181,13 +184,13 @@ __global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const i
     }
 }
 
-template <int TMAX>
+template <int TMAX, int DR>
 __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
                                                              const int64_t* __restrict__ lens, const float* __restrict__ dS,
                                                              const float* __restrict__ dloss, float gamma1, float gamma2, float gamma3,
                                                              float* __restrict__ dfeat, float* __restrict__ dwemb, int B, int D, int T, int S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    PairSmem<TMAX, DR>& sm = *reinterpret_cast<PairSmem<TMAX, DR>*>(smem_raw);
     __shared__ float dot[TMAX];
     const int j = blockIdx.x, i = blockIdx.y;
     const float g = dS[(size_t)j * B + i] * dloss[0] * gamma3;     // d loss / d log-sum-exp of this pair
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
     const float scale = rsqrtf((float)D), eps = 1e-8f;
     const float* fj = feat + (size_t)j * D * S;
     float a1[TMAX];
-    pair_forward<TMAX>(sm, fj, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
+    pair_forward<TMAX, DR>(sm, fj, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
 
     // --- d cos, then d num / d n1 / d n2 per word (uniform, recomputed by every thread from LDS) ---
     float dnum[TMAX], dn1[TMAX], dn2[TMAX];
@@ -306,22 +309,29 @@ __global__ __launch_bounds__(256) void sent_scores_kernel(const float* __restric
                                                           float eps, float* __restrict__ sim, float* __restrict__ dots,
                                                           float* __restrict__ norms, int B, int D) {
     // norms[0..B) = |cnn_j|, norms[B..2B) = |rnn_i|; dots[j][i] = <cnn_j, rnn_i>; sim = gamma3 * dots / max(nc*nr, eps)
-    __shared__ float nc[kMaxB], nr[kMaxB];
-    for (int k = threadIdx.x; k < 2 * B; k += 256) {
-        const float* p = (k < B ? cnn + (size_t)k * D : rnn + (size_t)(k - B) * D);
-        float s = 0.f;
-        for (int d = 0; d < D; ++d) s += p[d] * p[d];
-        s = sqrtf(s);
-        (k < B ? nc[k] : nr[k - B]) = s;
-        norms[k] = s;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < B * B; e += 256) {
-        const int j = e / B, i = e - j * B;
-        float s = 0.f;
-        for (int d = 0; d < D; ++d) s += cnn[(size_t)j * D + d] * rnn[(size_t)i * D + d];
-        dots[e] = s;
-        sim[e] = s / fmaxf(nc[j] * nr[i], eps) * gamma3;      // sentence_loss.py:33-38
+    // one workgroup per image j, one wave per caption i (lanes stride the embedding); every workgroup needs all |rnn_i| and
+    // recomputes them on the way (B*D reads, L2-resident)
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* cj = cnn + (size_t)j * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += cj[d] * cj[d];
+    const float ncj = sqrtf(wave_sum(s));
+    if (threadIdx.x == 0) norms[j] = ncj;
+    for (int i = wave; i < B; i += 4) {
+        const float* ri = rnn + (size_t)i * D;
+        float dt = 0.f, rr = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float r = ri[d];
+            dt += cj[d] * r;
+            rr += r * r;
+        }
+        dt = wave_sum(dt);
+        const float nri = sqrtf(wave_sum(rr));
+        if (lane == 0) {
+            dots[(size_t)j * B + i] = dt;
+            sim[(size_t)j * B + i] = dt / fmaxf(ncj * nri, eps) * gamma3;      // sentence_loss.py:33-38
+            if (j == 0) norms[B + i] = nri;
+        }
     }
 }
 
@@ -360,15 +370,15 @@ __global__ __launch_bounds__(kNT) void func_attn_fwd_kernel(const float* __restr
     PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
     const int b = blockIdx.x;
     float a1[TMAX];
-    pair_forward<TMAX>(sm, context + (size_t)b * D * S, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
+    pair_forward<TMAX, kNT>(sm, context + (size_t)b * D * S, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
     if (threadIdx.x < D)
         for (int w = 0; w < L; ++w) wctx[((size_t)b * D + threadIdx.x) * L + w] = sm.c[threadIdx.x][w];
     if (threadIdx.x < S)
         for (int w = 0; w < L; ++w) attn[((size_t)b * L + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
 }
 
-template <int TMAX>
-constexpr size_t pair_smem_bytes() { return sizeof(PairSmem<TMAX>); }
+template <int TMAX, int DR = kNT>
+constexpr size_t pair_smem_bytes() { return sizeof(PairSmem<TMAX, DR>); }
 
 }  // namespace
 
@@ -385,13 +395,19 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     AGAN_REQUIRE(T >= 1 && T <= 32, "words_loss: seq_len %d > 32", T);
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);
-    if (T <= 16) {
-        static const hipError_t attr_16_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>()); (void)attr_16_;
-        hipLaunchKernelGGL((words_pair_fwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
-    } else {
-        static const hipError_t attr_32_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>()); (void)attr_32_;
-        hipLaunchKernelGGL((words_pair_fwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, gamma1, gamma2, gamma3, sim, attn_maps, B, D, T, S);
-    }
+#define AGAN_PAIR_FWD(TM, DRR)                                                                                                          \
+    do {                                                                                                                               \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<TM, DRR>),             \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<TM, DRR>()); \
+        (void)attr_;                                                                                                                   \
+        const size_t smem_ = pair_smem_bytes<TM, DRR>();                                                                               \
+        hipLaunchKernelGGL((words_pair_fwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, wemb, lens, gamma1,  \
+                           gamma2, gamma3, sim, attn_maps, B, D, T, S);                                                                \
+    } while (0)
+    if (T <= 12 && D <= 256) AGAN_PAIR_FWD(12, 256);
+    else if (T <= 16) AGAN_PAIR_FWD(16, kNT);
+    else AGAN_PAIR_FWD(32, kNT);
+#undef AGAN_PAIR_FWD
     hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, lambda, loss, save, B);
     return check_launch("words_loss_fwd");
 }
@@ -402,13 +418,19 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
     AGAN_REQUIRE(B >= 1 && B <= kMaxB && D <= kNT && S <= kNT && T <= 32, "words_loss_bwd: shape out of range");
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);     // dfeat / dwemb must be zero-initialised by the caller (they are accumulated with atomics)
-    if (T <= 16) {
-        static const hipError_t attr_16_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>()); (void)attr_16_;
-        hipLaunchKernelGGL((words_pair_bwd_kernel<16>), grid, dim3(kNT), pair_smem_bytes<16>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
-    } else {
-        static const hipError_t attr_32_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>()); (void)attr_32_;
-        hipLaunchKernelGGL((words_pair_bwd_kernel<32>), grid, dim3(kNT), pair_smem_bytes<32>(), st, feat, wemb, lens, save, dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);
-    }
+#define AGAN_PAIR_BWD(TM, DRR)                                                                                                          \
+    do {                                                                                                                               \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<TM, DRR>),             \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<TM, DRR>()); \
+        (void)attr_;                                                                                                                   \
+        const size_t smem_ = pair_smem_bytes<TM, DRR>();                                                                               \
+        hipLaunchKernelGGL((words_pair_bwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, wemb, lens, save,   \
+                           dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);                                                   \
+    } while (0)
+    if (T <= 12 && D <= 256) AGAN_PAIR_BWD(12, 256);
+    else if (T <= 16) AGAN_PAIR_BWD(16, kNT);
+    else AGAN_PAIR_BWD(32, kNT);
+#undef AGAN_PAIR_BWD
     return check_launch("words_loss_bwd");
 }
 
@@ -421,7 +443,7 @@ int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64
     float* dots = save + B * B;       // [B*B]
     float* norms = dots + B * B;      // [2B]
     // sim is staged in dS's storage, then overwritten by the CE kernel's gradient
-    hipLaunchKernelGGL(sent_scores_kernel, dim3(1), dim3(256), 0, st, cnn_code, rnn_code, gamma3, eps, dS, dots, norms, B, D);
+    hipLaunchKernelGGL(sent_scores_kernel, dim3(B), dim3(256), 0, st, cnn_code, rnn_code, gamma3, eps, dS, dots, norms, B, D);
     hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, dS, class_ids, lambda, loss, dS, B);
     return check_launch("sent_loss_fwd");
 }

@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
 __global__ void adam_tick_kernel(int* __restrict__ step, float* __restrict__ coef, double lr, double b1, double b2) {
     const int t = *step + 1;
     *step = t;
-    const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+    // beta^t by squaring (double): the libm pow() sequence took 28 us on this single lane, 4 x per step
+    double p1 = 1.0, p2 = 1.0, q1 = b1, q2 = b2;
+    for (int e = t; e > 0; e >>= 1) {
+        if (e & 1) { p1 *= q1; p2 *= q2; }
+        q1 *= q1; q2 *= q2;
+    }
+    const double bc1 = 1.0 - p1, bc2 = 1.0 - p2;
     coef[0] = (float)(lr / bc1);
     coef[1] = (float)(1.0 / sqrt(bc2));
 }

@@ -39,8 +39,24 @@ class StandInImageEncoder(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
 
+    @staticmethod
+    def _pool_matrix(n_in: int, n_out: int, device) -> Tensor:
+        """adaptive_avg_pool windows (start = floor(i*n_in/n_out), end = ceil((i+1)*n_in/n_out)) as an [n_out, n_in] matrix"""
+        P = torch.zeros(n_out, n_in)
+        for i in range(n_out):
+            lo, hi = (i * n_in) // n_out, -((-(i + 1) * n_in) // n_out)
+            P[i, lo:hi] = 1.0 / (hi - lo)
+        return P.to(device)
+
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor]:
-        r = F.adaptive_avg_pool2d(x, 17)
+        # adaptive 17x17 average pooling as two small matrix products: same values as F.adaptive_avg_pool2d, but the backward
+        # is a pair of GEMMs instead of torch's float-atomic scatter kernel (slow at 256x256, and not run-to-run reproducible)
+        H, W = x.shape[-2:]
+        key = (H, W, x.device)
+        if getattr(self, "_pool_key", None) != key:
+            self._pool_key, self._pool = key, (self._pool_matrix(H, 17, x.device), self._pool_matrix(W, 17, x.device))
+        Ph, Pw = self._pool
+        r = torch.matmul(torch.matmul(Ph, x), Pw.t())
         regions = torch.einsum("ec,bchw->behw", self.emb_features, r)
         code = regions.mean(dim=(2, 3)) @ self.emb_cnn_code.t()
         return regions, code

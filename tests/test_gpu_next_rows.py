@@ -220,3 +220,34 @@ def test_hip_graph_replay_equals_eager_steps():
     for da, db in zip(a.Ds, b.Ds):
         for (k, va), (_, vb) in zip(da.state_dict().items(), db.state_dict().items()):
             assert_close(vb.double(), va.double(), 1e-4, f"D {k}")
+
+
+def test_side_stream_weight_gradients_match_inline():
+    """overlap_weight_gradients forks every conv weight/bias gradient onto a side stream (joined by the optimiser step).
+    Step 1: the discriminators (deterministic kernels, same inputs) must land bit for bit where the inline path lands, the
+    generator to the rounding of its float-atomic attention / DAMSM backward.  Step 2 (which sees that rounding through the
+    fake images and Adam's normalisation) to the north-star tolerance."""
+    def run(side):
+        G, Ds, enc, d = _setup(13)
+        st = TR.GanTrainStep(G, Ds, enc)
+        st.overlap_weight_gradients = side
+        o1 = {k: v.clone() for k, v in _one(st, d).items() if k != "fake_imgs"}
+        torch.cuda.synchronize()
+        s1 = ([{k: v.clone() for k, v in m.state_dict().items()} for m in st.Ds], {k: v.clone() for k, v in st.G.state_dict().items()})
+        o2 = _one(st, d)
+        torch.cuda.synchronize()
+        return st, o1, s1, o2
+    a, oa1, (da1, ga1), oa2 = run(False)
+    b, ob1, (db1, gb1), ob2 = run(True)
+    for k in ("d_loss0", "d_loss1", "d_loss2", "g_total"):
+        assert float(oa1[k]) == float(ob1[k]), k
+    for x, y in zip(da1, db1):
+        for k in x:
+            assert torch.equal(x[k], y[k]), f"D {k} after step 1"
+    for k in ga1:
+        assert_close(gb1[k].double(), ga1[k].double(), 1e-5, f"G {k} after step 1")
+    for k in ("d_loss0", "d_loss1", "d_loss2", "g_total"):
+        assert_close(ob2[k], oa2[k], 1e-5, k)
+    for m, n in zip(a.Ds + [a.G], b.Ds + [b.G]):
+        for (k, va), (_, vb) in zip(m.state_dict().items(), n.state_dict().items()):
+            assert_close(vb.double(), va.double(), RTOL, f"{k} after step 2")

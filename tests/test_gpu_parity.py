@@ -328,6 +328,28 @@ def test_words_loss_single_word_and_metric_shape():
     assert_close(wd.grad, wr.grad, RTOL, "dwemb B=24")
 
 
+@pytest.mark.parametrize("T_,D_", [(14, 32), (20, 40), (8, 300)])
+def test_words_loss_kernel_variants_vs_oracle(T_, D_):
+    """the pair kernels are instantiated for seq_len <= 12 / nef <= 256 (metric config), seq_len <= 16 and seq_len <= 32:
+    every instance against the oracle, forward and backward (the golden fixtures all take the first one)"""
+    WL = importlib.import_module("attention-gan_amd.losses.words_loss").WordsLoss
+    gen = torch.Generator().manual_seed(T_ * 100 + D_)
+    B = 3
+    feat, wemb = torch.randn(B, D_, 17, 17, generator=gen), torch.randn(B, D_, T_, generator=gen)
+    lens = torch.tensor([T_, max(1, T_ // 2), 3])
+    fr, wr = feat.clone().requires_grad_(True), wemb.clone().requires_grad_(True)
+    lr, maps_r = O.words_loss(fr, wr, torch.arange(B), lens.tolist(), None)
+    lr.backward()
+    fd, wd = feat.to(DEV).requires_grad_(True), wemb.to(DEV).requires_grad_(True)
+    ld, maps_d = WL(torch.device(DEV)).get_loss(fd, wd, torch.arange(B, device=DEV), lens, None)
+    ld.backward()
+    assert_close(ld, lr, TOL.tight, "loss")
+    for i, (md, mr) in enumerate(zip(maps_d, maps_r)):
+        assert_close(md, mr, TOL.tight, f"map{i}")
+    assert_close(fd.grad, fr.grad, RTOL, "dfeat")
+    assert_close(wd.grad, wr.grad, RTOL, "dwemb")
+
+
 def test_small_losses_vs_golden():
     KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
     g = load("a10_losses")
