@@ -136,19 +136,42 @@ def conv_geoms(kind: str, B: int, Cin: int, H: int, W: int, Cout: int, k: int):
 
 # Packed weights are cached per owning module (a plain dict the module passes in): a parameter is re-packed only when
 # it changed -- in-place version bump (load_state_dict), new storage (.to(), FlatAdam re-homing) or an optimiser step
-# that wrote through the raw pointer and therefore bumped the global epoch.  Without a cache dict every call re-packs.
+# that wrote through the raw pointer.  Optimiser steps are tracked per flat buffer (register_flat): the generator's Adam
+# step must not invalidate the discriminators' packed weights.  Writes through a raw pointer into memory that is not a
+# registered flat buffer bump the global epoch instead.  Without a cache dict every call re-packs.
 _WEIGHT_EPOCH = [0]
+_FLAT_RANGES: list = []          # [start address, end address, epoch]
 
 
 def bump_weight_epoch() -> None:
     _WEIGHT_EPOCH[0] += 1
 
 
+def register_flat(flat: Tensor) -> None:
+    """Declare a flat parameter buffer whose views are conv/linear weights and which agan_adam_step updates in place."""
+    start = flat.data_ptr()
+    end = start + flat.numel() * flat.element_size()
+    # a buffer registered earlier that overlaps this one has been freed (the allocator handed its memory out again): drop it,
+    # and start above every epoch seen so far so that no cached pack of recycled memory can look fresh
+    top = max([r[2] for r in _FLAT_RANGES] + [0])
+    _FLAT_RANGES[:] = [r for r in _FLAT_RANGES if r[1] <= start or r[0] >= end]
+    _FLAT_RANGES.append([start, end, top + 1])
+
+
+def _flat_range(ptr: int):
+    for r in _FLAT_RANGES:
+        if r[0] <= ptr < r[1]:
+            return r
+    return None
+
+
 def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     cout, cin, kh, kw = w.shape
     prec = _PRECISION[0]
-    ver = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0], cout, cin, kh, kw)
     hit = cache.get((mode, prec)) if cache is not None else None
+    ptr = w.data_ptr()
+    rng = hit[2] if (hit is not None and hit[0][0] == ptr) else _flat_range(ptr)
+    ver = (ptr, w._version, _WEIGHT_EPOCH[0], rng[2] if rng is not None else -1, cout, cin, kh, kw)
     if hit is not None and hit[0] == ver:
         return hit[1]
     n = L.load().agan_packed_weight_bytes(mode, cout, cin, kh, kw, prec)
@@ -158,7 +181,7 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     wk = hit[1] if reuse else torch.empty(n, dtype=torch.uint8, device=w.device)
     L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, prec, _stream())
     if cache is not None:
-        cache[(mode, prec)] = (ver, wk)
+        cache[(mode, prec)] = (ver, wk, rng)
     return wk
 
 
@@ -671,4 +694,8 @@ def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor,
         raise L.AganError("adam_step_: step_state must be an int32 device tensor of 4 elements")
     L.call("agan_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(step_state), float(lr),
            float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
-    bump_weight_epoch()
+    rng = _flat_range(param.data_ptr())
+    if rng is not None:
+        rng[2] += 1
+    else:
+        bump_weight_epoch()

@@ -39,6 +39,8 @@ class FlatAdam:
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._agan_grad_dst = HF.GradDst(self.grad, o, p.numel())   # backward kernels write here directly
+        if self.flat.is_cuda:
+            HF.register_flat(self.flat)        # packed-weight caches follow THIS buffer's Adam steps only
         self.step_count = 0
         # device-resident step counter + bias-correction coefficients (see agan_adam_step): advanced by the kernel itself, so a
         # captured HIP graph keeps counting on replay; step_count mirrors it on the host for state_dict()
