@@ -488,7 +488,7 @@ class _AttentionFn(Function):
         dattn = _dev(dattn, "attention dattn") if dattn is not None else None
         dimages, dwords = torch.empty_like(images), torch.empty_like(words)
         dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, images)
-        nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T)
+        nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T, H * W)
         ws, wsp = _ws(nbytes, images)
         L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
                _p(dimages), _p(dwords), _p(dwbuf), B, C, E, T, H * W, wacc, wsp, nbytes, _stream())
@@ -637,10 +637,12 @@ class _WordsLossFn(Function):
         B, D = feat.shape[0], feat.shape[1]
         S = feat.numel() // (B * D)
         T = wemb.shape[2]
-        dfeat, dwemb = torch.zeros_like(feat), torch.zeros_like(wemb)
+        dfeat, dwemb = torch.empty_like(feat), torch.empty_like(wemb)
         dl = dloss.to(torch.float32).contiguous()
+        nbytes = L.load().agan_words_loss_bwd_ws_bytes(B, D, T, S)
+        ws, wsp = _ws(nbytes, feat)
         L.call("agan_words_loss_bwd", _p(feat), _p(wemb), _p(lens), _p(save), _p(dl), *ctx.hp, _p(dfeat), _p(dwemb),
-               B, D, T, S, _stream())
+               B, D, T, S, wsp, nbytes, _stream())
         return dfeat, dwemb, None, None, None, None, None, None
 
 

@@ -15,16 +15,28 @@ namespace {
 constexpr int kMaxC = 64;   // LDS budget for the projected words: kMaxC * TMAX floats
 
 // proj[b,c,t] = sum_e w[c,e] * words[b,e,t]        (attention.py:50-52: the 1x1 conv on the word axis)
+// one wave per (b, c): lanes stride the embedding axis, the T partial sums meet in one transposing butterfly
+template <int TMAX>
 __global__ __launch_bounds__(256) void attn_proj_kernel(const float* __restrict__ words, const float* __restrict__ w,
                                                         float* __restrict__ proj, int B, int C, int E, int T) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C * T) return;
-    const int t = i % T, c = (i / T) % C, b = i / (T * C);
+    const int lane = threadIdx.x & 63;
+    const int bc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bc >= B * C) return;                                  // wave-uniform
+    const int b = bc / C, c = bc - b * C;
     const float* wr = w + (size_t)c * E;
-    const float* wd = words + (size_t)b * E * T + t;
-    float s = 0.f;
-    for (int e = 0; e < E; ++e) s += wr[e] * wd[(size_t)e * T];
-    proj[i] = s;
+    const float* wd = words + (size_t)b * E * T;
+    float part[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) part[t] = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float wv = wr[e];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) part[t] += wv * wd[(size_t)e * T + t];
+    }
+    int t_own;
+    const float r = wave_sum_scatter<TMAX>(part, lane, t_own);
+    if ((lane & (64 / TMAX - 1)) == 0 && t_own < T) proj[(size_t)bc * T + t_own] = r;
 }
 
 template <int TMAX>
@@ -79,19 +91,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
 }
 
-// backward of the streaming pass.  dproj is accumulated per block in LDS, then one global atomic per (c,t) per block.
+// backward of the streaming pass.  The d(proj) contribution of a workgroup's 256 pixels is reduced WITHOUT atomics so that
+// the result is bit-reproducible: a butterfly per channel inside each wave, one LDS row per wave, a fixed-order sum of the
+// four rows, and one partial [C][T] slab per workgroup that attn_dproj_reduce_kernel sums in block order.
 template <int TMAX>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ images, const float* __restrict__ proj,
                                                        const float* __restrict__ attn, const float* __restrict__ dctx,
                                                        const float* __restrict__ dattn, float scale, float* __restrict__ dimages,
-                                                       float* __restrict__ dproj, int C, int T, int HW) {
-    __shared__ float pj[kMaxC][TMAX];
-    __shared__ float acc[kMaxC][TMAX];
+                                                       float* __restrict__ dproj_part, int C, int T, int HW) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float (*pj)[TMAX] = reinterpret_cast<float (*)[TMAX]>(smem_raw);                               // [kMaxC][TMAX]
+    float (*acc)[kMaxC][TMAX] = reinterpret_cast<float (*)[kMaxC][TMAX]>(smem_raw + sizeof(float) * kMaxC * TMAX);   // [4 waves]
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < C * TMAX; i += 256) {
         const int c = i / TMAX, t = i - c * TMAX;
         pj[c][t] = t < T ? proj[((size_t)b * C + c) * T + t] : 0.f;
-        acc[c][t] = 0.f;
     }
     __syncthreads();
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int t = 0; t < TMAX; ++t) ds[t] = a[t] * (da[t] - dot) * scale;
     const float* img = images + (size_t)b * C * HW + pp;
     float* di = dimages + (size_t)b * C * HW + pp;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = 0; c < C; ++c) {
         const float iv = live ? img[(size_t)c * HW] : 0.f;
         const float dv = (live && dc) ? dc[(size_t)c * HW] : 0.f;
@@ -132,13 +146,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int t = 0; t < TMAX; ++t) part[t] = dv * a[t] + iv * ds[t];
         int t_own;
         const float r = wave_sum_scatter<TMAX>(part, lane, t_own);       // TMAX + 1 shuffles per channel, not 6 * TMAX
-        if ((lane & (64 / TMAX - 1)) == 0 && t_own < T) atomicAdd(&acc[c][t_own], r);
+        if ((lane & (64 / TMAX - 1)) == 0) acc[wave][c][t_own] = r;
     }
     __syncthreads();
+    float* dst = dproj_part + ((size_t)b * gridDim.x + blockIdx.x) * C * T;
     for (int i = threadIdx.x; i < C * T; i += 256) {
         const int c = i / T, t = i - c * T;
-        atomicAdd(&dproj[((size_t)b * C + c) * T + t], acc[c][t]);
+        dst[i] = ((acc[0][c][t] + acc[1][c][t]) + acc[2][c][t]) + acc[3][c][t];
     }
+}
+
+// dproj[b][c][t] = sum over the pixel workgroups of their partial slabs, in workgroup order
+__global__ __launch_bounds__(256) void attn_dproj_reduce_kernel(const float* __restrict__ part, float* __restrict__ dproj, int B, int nblk, int CT) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * CT) return;
+    const int b = i / CT, e = i - b * CT;
+    const float* p = part + (size_t)b * nblk * CT + e;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += p[(size_t)k * CT];
+    dproj[i] = s;
 }
 
 // dwords[b,e,t] = sum_c w[c,e] dproj[b,c,t];   dw[c,e] = sum_{b,t} dproj[b,c,t] words[b,e,t]
@@ -172,7 +198,9 @@ int agan_attn_fwd(const float* images, const float* words, const float* w, const
     AGAN_REQUIRE(C <= kMaxC, "attn_fwd: nc_in %d > %d", C, kMaxC);
     AGAN_REQUIRE(T <= 64, "attn_fwd: seq_len %d > 64", T);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(attn_proj_kernel, dim3(cdiv(B * C * T, 256)), dim3(256), 0, st, words, w, proj, B, C, E, T);
+    if (T <= 16) hipLaunchKernelGGL((attn_proj_kernel<16>), dim3(cdiv(B * C, 4)), dim3(256), 0, st, words, w, proj, B, C, E, T);
+    else if (T <= 32) hipLaunchKernelGGL((attn_proj_kernel<32>), dim3(cdiv(B * C, 4)), dim3(256), 0, st, words, w, proj, B, C, E, T);
+    else hipLaunchKernelGGL((attn_proj_kernel<64>), dim3(cdiv(B * C, 4)), dim3(256), 0, st, words, w, proj, B, C, E, T);
     dim3 grid(cdiv(HW, 256), B);
     if (T <= 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);
     else if (T <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);
@@ -180,27 +208,40 @@ int agan_attn_fwd(const float* images, const float* words, const float* w, const
     return check_launch("attn_fwd");
 }
 
-size_t agan_attn_bwd_ws_bytes(int B, int C, int T) { return (size_t)B * C * T * sizeof(float); }
+size_t agan_attn_bwd_ws_bytes(int B, int C, int T, int HW) {
+    if (B <= 0 || C <= 0 || T <= 0 || HW <= 0) return 0;
+    return ((size_t)B * C * T + (size_t)B * cdiv(HW, 256) * C * T) * sizeof(float);       // dproj + one partial slab per workgroup
+}
 
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw, int B, int C,
                   int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     AGAN_REQUIRE(images && words && w && proj && attn && dimages && dwords && dw && ws, "attn_bwd: null pointer");
+    AGAN_REQUIRE(B > 0 && C > 0 && E > 0 && T > 0 && HW > 0, "attn_bwd: non-positive dimension");
     AGAN_REQUIRE(C <= kMaxC && T <= 64, "attn_bwd: nc_in %d / seq_len %d out of range", C, T);
-    if (ws_bytes < agan_attn_bwd_ws_bytes(B, C, T)) {
+    if (ws_bytes < agan_attn_bwd_ws_bytes(B, C, T, HW)) {
         set_error("attn_bwd: workspace too small");
         return AGAN_EWORKSPACE;
     }
     hipStream_t st = as_stream(stream);
     float* dproj = static_cast<float*>(ws);
-    if (hipMemsetAsync(dproj, 0, agan_attn_bwd_ws_bytes(B, C, T), st) != hipSuccess) {
-        set_error("attn_bwd: memset failed");
-        return AGAN_ELAUNCH;
-    }
-    dim3 grid(cdiv(HW, 256), B);
-    if (T <= 16) hipLaunchKernelGGL((attn_bwd_kernel<16>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
-    else if (T <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
-    else hipLaunchKernelGGL((attn_bwd_kernel<64>), grid, dim3(256), 0, st, images, proj, attn, dctx, dattn, scale, dimages, dproj, C, T, HW);
+    float* part = dproj + (size_t)B * C * T;
+    const int nblk = cdiv(HW, 256);
+    dim3 grid(nblk, B);
+#define AGAN_ATTN_BWD(TM)                                                                                                            \
+    do {                                                                                                                             \
+        const size_t smem_ = sizeof(float) * kMaxC * TM * 5;                                                                         \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TM>),                      \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_);                 \
+        (void)attr_;                                                                                                                 \
+        hipLaunchKernelGGL((attn_bwd_kernel<TM>), grid, dim3(256), smem_, st, images, proj, attn, dctx, dattn, scale, dimages, part, \
+                           C, T, HW);                                                                                                \
+    } while (0)
+    if (T <= 16) AGAN_ATTN_BWD(16);
+    else if (T <= 32) AGAN_ATTN_BWD(32);
+    else AGAN_ATTN_BWD(64);
+#undef AGAN_ATTN_BWD
+    hipLaunchKernelGGL(attn_dproj_reduce_kernel, dim3(cdiv(B * C * T, 256)), dim3(256), 0, st, part, dproj, B, nblk, C * T);
     hipLaunchKernelGGL(attn_bwd_words_kernel, dim3(cdiv(B * E * T + C * E, 256)), dim3(256), 0, st, words, w, dproj, dwords, dw, B, C, E, T, accumulate);
     return check_launch("attn_bwd");
 }

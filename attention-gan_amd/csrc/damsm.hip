@@ -188,13 +188,21 @@ template <int TMAX, int DR>
 __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
                                                              const int64_t* __restrict__ lens, const float* __restrict__ dS,
                                                              const float* __restrict__ dloss, float gamma1, float gamma2, float gamma3,
-                                                             float* __restrict__ dfeat, float* __restrict__ dwemb, int B, int D, int T, int S) {
+                                                             float* __restrict__ part_f, float* __restrict__ part_w, int B, int D, int T, int S) {
+    // No atomics anywhere (bit-reproducible gradients): the pair writes its contribution to dfeat[j] into slab part_f[j][i] and
+    // its contribution to dwemb[i] into part_w[i][j]; pair_slab_sum_kernel adds the B slabs of each row in index order.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PairSmem<TMAX, DR>& sm = *reinterpret_cast<PairSmem<TMAX, DR>*>(smem_raw);
-    __shared__ float dot[TMAX];
+    __shared__ float dotw[kNT / 64][TMAX];
     const int j = blockIdx.x, i = blockIdx.y;
     const float g = dS[(size_t)j * B + i] * dloss[0] * gamma3;     // d loss / d log-sum-exp of this pair
-    if (g == 0.f) return;                                          // masked pair (uniform across the workgroup)
+    float* pf = part_f + ((size_t)j * B + i) * D * S;
+    float* pw = part_w + ((size_t)i * B + j) * D * T;
+    if (g == 0.f) {                                                // masked pair (uniform across the workgroup): zero slabs
+        for (int e = threadIdx.x; e < D * S; e += kNT) pf[e] = 0.f;
+        for (int e = threadIdx.x; e < D * T; e += kNT) pw[e] = 0.f;
+        return;
+    }
     const int L = min((int)lens[i], T);
     const int tid = threadIdx.x, lane = tid & 63;
     const float scale = rsqrtf((float)D), eps = 1e-8f;
@@ -238,7 +246,6 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
             sm.c[tid][w] = dnum[w] * ev + (sm.n2[w] > 0.f ? dn2[w] * cv / sm.n2[w] : 0.f);
         }
     }
-    if (tid < TMAX) dot[tid] = 0.f;
     __syncthreads();
     // --- thread r: da2[w] = sum_d f[d][r] dc[d][w];  dot[w] = sum_r a2 da2 ---
     const int r = tid;
@@ -256,9 +263,17 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
 #pragma unroll
     for (int w = 0; w < TMAX; ++w) {
         const float v = wave_sum(a2r[w] * da2[w]);
-        if (lane == 0 && w < L) atomicAdd(&dot[w], v);
+        if (lane == 0) dotw[tid >> 6][w] = v;
     }
     __syncthreads();
+    float dot[TMAX];
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < kNT / 64; ++q) v += dotw[q][w];          // fixed order over the five waves
+        dot[w] = v;
+    }
     // softmax-over-regions backward, then softmax-over-words backward -> ds (gradient of the scaled score)
     float ds[TMAX];
     {
@@ -273,12 +288,12 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
     }
     // --- dfeat[j][d][r] += sum_w dc[d][w] a2[r][w] + ds[r][w] e[d][w]   (coalesced along r) ---
     if (rlive) {
-        float* dfj = dfeat + (size_t)j * D * S + r;
+        float* dfj = pf + r;
         for (int d = 0; d < D; ++d) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < TMAX; ++w) v += sm.c[d][w] * a2r[w] + ds[w] * sm.e[d][w];
-            atomicAdd(dfj + (size_t)d * S, v);
+            dfj[(size_t)d * S] = v;
         }
     }
     __syncthreads();                 // everyone is done reading a2 (registers now) -> reuse its storage for ds
@@ -295,10 +310,21 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
 #pragma unroll
             for (int w = 0; w < TMAX; ++w) de[w] += fv * sm.a2[q][w];
         }
-        float* dwi = dwemb + ((size_t)i * D + tid) * T;
+        float* dwi = pw + (size_t)tid * T;
 #pragma unroll
         for (int w = 0; w < TMAX; ++w)
-            if (w < L) atomicAdd(dwi + w, de[w]);
+            if (w < T) dwi[w] = w < L ? de[w] : 0.f;
+    }
+}
+
+// out[row][e] = sum_k part[row][k][e], k = 0..B-1 in order (row = image for dfeat, caption for dwemb)
+__global__ __launch_bounds__(256) void pair_slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int n) {
+    const int row = blockIdx.y;
+    const float* p = part + (size_t)row * B * n;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < B; ++k) s += p[(size_t)k * n + e];
+        out[(size_t)row * n + e] = s;
     }
 }
 
@@ -412,12 +438,24 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     return check_launch("words_loss_fwd");
 }
 
+size_t agan_words_loss_bwd_ws_bytes(int B, int D, int T, int S) {
+    if (B <= 0 || D <= 0 || T <= 0 || S <= 0) return 0;
+    return (size_t)B * B * D * ((size_t)S + T) * sizeof(float);        // one dfeat slab and one dwemb slab per (image, caption) pair
+}
+
 int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* lens, const float* save, const float* dloss, float gamma1,
-                        float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb, int B, int D, int T, int S, void* stream) {
-    AGAN_REQUIRE(feat && wemb && lens && save && dloss && dfeat && dwemb, "words_loss_bwd: null pointer");
+                        float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb, int B, int D, int T, int S, void* ws,
+                        size_t ws_bytes, void* stream) {
+    AGAN_REQUIRE(feat && wemb && lens && save && dloss && dfeat && dwemb && ws, "words_loss_bwd: null pointer");
     AGAN_REQUIRE(B >= 1 && B <= kMaxB && D <= kNT && S <= kNT && T <= 32, "words_loss_bwd: shape out of range");
+    if (ws_bytes < agan_words_loss_bwd_ws_bytes(B, D, T, S)) {
+        set_error("words_loss_bwd: workspace %zu < %zu", ws_bytes, agan_words_loss_bwd_ws_bytes(B, D, T, S));
+        return AGAN_EWORKSPACE;
+    }
     hipStream_t st = as_stream(stream);
-    dim3 grid(B, B);     // dfeat / dwemb must be zero-initialised by the caller (they are accumulated with atomics)
+    float* part_f = static_cast<float*>(ws);
+    float* part_w = part_f + (size_t)B * B * D * S;
+    dim3 grid(B, B);
 #define AGAN_PAIR_BWD(TM, DRR)                                                                                                          \
     do {                                                                                                                               \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_kernel<TM, DRR>),             \
@@ -425,12 +463,14 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
         (void)attr_;                                                                                                                   \
         const size_t smem_ = pair_smem_bytes<TM, DRR>();                                                                               \
         hipLaunchKernelGGL((words_pair_bwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, wemb, lens, save,   \
-                           dloss, gamma1, gamma2, gamma3, dfeat, dwemb, B, D, T, S);                                                   \
+                           dloss, gamma1, gamma2, gamma3, part_f, part_w, B, D, T, S);                                                 \
     } while (0)
     if (T <= 12 && D <= 256) AGAN_PAIR_BWD(12, 256);
     else if (T <= 16) AGAN_PAIR_BWD(16, kNT);
     else AGAN_PAIR_BWD(32, kNT);
 #undef AGAN_PAIR_BWD
+    hipLaunchKernelGGL(pair_slab_sum_kernel, dim3(std::min(cdiv(D * S, 256), 64), B), dim3(256), 0, st, part_f, dfeat, B, D * S);
+    hipLaunchKernelGGL(pair_slab_sum_kernel, dim3(std::min(cdiv(D * T, 256), 64), B), dim3(256), 0, st, part_w, dwemb, B, D * T);
     return check_launch("words_loss_bwd");
 }
 

@@ -149,8 +149,9 @@ int agan_glu_bwd(const float* x, const float* dout, float* dx, int B, int C, int
  * ---------------------------------------------------------------------------------------------- */
 int agan_attn_fwd(const float* images, const float* words, const float* w, const int64_t* mask, float scale,
                   float* proj, float* ctx, float* attn, int B, int C, int E, int T, int HW, void* stream);
-/* dctx / dattn may be NULL (treated as zero).  Outputs dimages[B,C,HW], dwords[B,E,T], dw[C,E].  ws: B*C*T floats. */
-size_t agan_attn_bwd_ws_bytes(int B, int C, int T);
+/* dctx / dattn may be NULL (treated as zero).  Outputs dimages[B,C,HW], dwords[B,E,T], dw[C,E].  No atomics: the projected-word
+ * gradient is reduced through per-workgroup slabs in `ws`, so the result is bit-reproducible. */
+size_t agan_attn_bwd_ws_bytes(int B, int C, int T, int HW);
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw,
                   int B, int C, int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -170,9 +171,12 @@ size_t agan_words_loss_save_elems(int B, int D, int T, int S);
 int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids,
                         float gamma1, float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps,
                         float* save, int B, int D, int T, int S, void* stream);
+/* backward: dfeat / dwemb are overwritten.  No atomics (bit-reproducible): each (image, caption) pair writes its contribution to a
+ * slab in `ws` (agan_words_loss_bwd_ws_bytes: B*B*D*(S+T) floats) and a second pass adds the B slabs of each row in index order. */
+size_t agan_words_loss_bwd_ws_bytes(int B, int D, int T, int S);
 int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* lens, const float* save, const float* dloss,
                         float gamma1, float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb,
-                        int B, int D, int T, int S, void* stream);
+                        int B, int D, int T, int S, void* ws, size_t ws_bytes, void* stream);
 int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, float gamma3, float lambda,
                        float eps, float* loss, float* save /* 2*B*B + 2*B floats */, int B, int D, void* stream);
 int agan_sent_loss_bwd(const float* cnn_code, const float* rnn_code, const float* save, const float* dloss, float gamma3,
