@@ -169,7 +169,9 @@ inline GatherPlan plan_gather(const Geom& g, int prec) {
     // fewer tiles than one round of resident workgroups: split K so that the grid is one full round, never just over it
     // (one block over a multiple of the slot count costs a whole extra round)
     int ks = 1;
-    if (tiles < slots) ks = std::max(1, std::min({slots / tiles, std::max(1, ktiles / 4), 32}));
+    // (and a workgroup keeps at least 16 K tiles: below that its prologue/epilogue and the slab traffic outweigh the extra
+    // parallelism: measured sweep of the split factor on the 4x4..32x32 discriminator layers)
+    if (tiles < slots) ks = std::max(1, std::min({slots / tiles, std::max(1, ktiles / 16), 32}));
     p.kchunk = cdiv(ktiles, ks) * bk;
     p.ksplit = cdiv(g.K, p.kchunk);
     p.slab = (size_t)g.B * g.Cout * g.OH * g.OW;
@@ -193,9 +195,16 @@ inline WgradPlan plan_wgrad(const Geom& g, bool needs_combine) {
     p.ncls = g.OS * g.OS;
     const int tiles = p.itiles * p.jtiles * p.ncls;
     const int ptiles = cdiv(g.Mtot, 32);
-    // split the pixel reduction so the grid is about two rounds of resident workgroups (256 CUs x 2), never one block over
+    // Split the pixel reduction so that the grid fills one or two rounds of resident workgroups (256 CUs x 2): whichever round
+    // count the tile count divides better, one round on a tie (half the slab traffic); a workgroup keeps >= 4 pixel tiles.
+    // Grids just over a round boundary (e.g. 576 workgroups) were up to 25% slower in the measured sweep.
     int ps = 1;
-    if (tiles < 1024) ps = std::max(1, std::min({1024 / tiles, std::max(1, ptiles / 4), 2048}));
+    if (tiles < 512) {
+        const int cap = std::max(1, ptiles / 4);
+        const int ps1 = std::max(1, std::min(512 / tiles, cap)), ps2 = std::max(1, std::min(1024 / tiles, cap));
+        const double fill1 = (double)tiles * ps1 / 512.0, fill2 = (double)tiles * ps2 / 1024.0;
+        ps = std::min(fill2 > fill1 + 1e-9 ? ps2 : ps1, 2048);
+    }
     p.pchunk = cdiv(ptiles, ps) * 32;
     p.psplit = cdiv(g.Mtot, p.pchunk);
     p.slab = ((size_t)p.ncls * g.Cout * g.K + 3) / 4 * 4;
