@@ -22,9 +22,13 @@ constexpr int kMaxB = 128;
 // <16, 320> instance fits two per CU = 512 slots, i.e. a second round for the last 64 pairs.
 template <int TMAX, int DR = kNT>
 struct PairSmem {
-    float e[DR][TMAX + 1];     // caption words   e[d][w]  (0 for w >= L)
-    float a2[kNT][TMAX + 1];   // attention       a2[r][w] (softmax over regions of gamma1 * softmax over words)
-    float c[DR][TMAX + 1];     // weighted context c[d][w]
+    // Row stride: the hot loops read whole rows that every lane shares (broadcast), so rows that are a multiple of 16 bytes let
+    // them go as ds_read_b128 (3 per row at TMAX = 12 instead of 12 ds_read_b32).  A 12-float stride also keeps the
+    // one-row-per-lane accesses at the 8-cycle minimum of a 1 KB wave access; 16- and 32-float strides would not, hence the pad.
+    static constexpr int LDW = (TMAX % 8 == 4) ? TMAX : TMAX + 1;
+    alignas(16) float e[DR][LDW];     // caption words   e[d][w]  (0 for w >= L)
+    alignas(16) float a2[kNT][LDW];   // attention       a2[r][w] (softmax over regions of gamma1 * softmax over words)
+    alignas(16) float c[DR][LDW];     // weighted context c[d][w]
     float num[TMAX], n1[TMAX], n2[TMAX], cosv[TMAX];
     float colmax[TMAX], colsum[TMAX];
     float red[8];
