@@ -155,7 +155,12 @@ def register_flat(flat: Tensor) -> None:
     # and start above every epoch seen so far so that no cached pack of recycled memory can look fresh
     top = max([r[2] for r in _FLAT_RANGES] + [0])
     _FLAT_RANGES[:] = [r for r in _FLAT_RANGES if r[1] <= start or r[0] >= end]
-    _FLAT_RANGES.append([start, end, top + 1])
+    _FLAT_RANGES.append([start, end, top + 1, [], None])     # [start, end, epoch, pack entries, device job table]
+
+
+def unregister_flat(flat: Tensor) -> None:
+    start = flat.data_ptr()
+    _FLAT_RANGES[:] = [r for r in _FLAT_RANGES if r[0] != start]
 
 
 def _flat_range(ptr: int):
@@ -165,15 +170,63 @@ def _flat_range(ptr: int):
     return None
 
 
+_PACK_JOB_DTYPE = [("w", "<u8"), ("wk", "<u8"), ("mode", "<i4"), ("cout", "<i4"), ("cin", "<i4"), ("kh", "<i4"), ("kw", "<i4"),
+                   ("first_block", "<i4")]          # include/agan.h: agan_pack_job
+
+
+def _pack_table(rng):
+    """device job table of a flat buffer's pack entries (built on the host, one H2D copy; rebuilt when an entry is added)"""
+    import numpy as np
+    entries = rng[3]
+    if rng[4] is None or rng[4][1] != len(entries):
+        if torch.cuda.is_current_stream_capturing():
+            raise L.AganError("packed-weight job table missing during HIP-graph capture: run a warm-up step and "
+                              "build_pack_tables() first (GanTrainStep.capture does)")
+        lib = L.load()
+        jobs = np.zeros(len(entries), dtype=_PACK_JOB_DTYPE)
+        first = 0
+        for i, e in enumerate(entries):
+            cout, cin, kh, kw = e["dims"]
+            jobs[i] = (e["ptr"], e["wk"].data_ptr(), e["mode"], cout, cin, kh, kw, first)
+            first += lib.agan_pack_job_blocks(e["mode"], cout, cin, kh, kw)
+        table = torch.from_numpy(jobs.view(np.uint8).copy()).to(entries[0]["wk"].device)
+        rng[4] = (table, len(entries), first)
+    return rng[4]
+
+
+def build_pack_tables() -> None:
+    """Build every missing job table now (host work + H2D copies), e.g. before capturing a HIP graph."""
+    for rng in _FLAT_RANGES:
+        if rng[3]:
+            _pack_table(rng)
+
+
+def _repack_group(rng) -> None:
+    """Re-pack every registered packed weight of one flat buffer in a single launch (agan_pack_weights).  After an optimiser
+    step all of them are stale at once, and most are a few KB: one launch instead of one ~10 us launch per tensor and mode."""
+    table, n, total = _pack_table(rng)
+    L.call("agan_pack_weights", _p(table), n, total, L.PREC_F32, _stream())
+    for e in rng[3]:
+        e["cache"][e["key"]] = ((e["ptr"], e["tver"], _WEIGHT_EPOCH[0], rng[2]) + e["dims"], e["wk"], rng)
+
+
 def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     cout, cin, kh, kw = w.shape
     prec = _PRECISION[0]
-    hit = cache.get((mode, prec)) if cache is not None else None
+    key = (mode, prec)
+    hit = cache.get(key) if cache is not None else None
     ptr = w.data_ptr()
     rng = hit[2] if (hit is not None and hit[0][0] == ptr) else _flat_range(ptr)
     ver = (ptr, w._version, _WEIGHT_EPOCH[0], rng[2] if rng is not None else -1, cout, cin, kh, kw)
     if hit is not None and hit[0] == ver:
         return hit[1]
+    if hit is not None and rng is not None and prec == L.PREC_F32 and hit[0][:2] == ver[:2] and hit[0][4:] == ver[4:] \
+            and any(e["cache"] is cache and e["key"] == key for e in rng[3]):
+        # same tensor, only the optimiser epoch moved: its whole group is stale -> one batched launch
+        _repack_group(rng)
+        hit = cache[key]
+        if hit[0] == ver:
+            return hit[1]
     n = L.load().agan_packed_weight_bytes(mode, cout, cin, kh, kw, prec)
     if n == 0:
         raise L.AganError(f"pack mode {mode} / precision {prec} does not take a {kh}x{kw} kernel")
@@ -181,7 +234,14 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
     wk = hit[1] if reuse else torch.empty(n, dtype=torch.uint8, device=w.device)
     L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, prec, _stream())
     if cache is not None:
-        cache[(mode, prec)] = (ver, wk, rng)
+        cache[key] = (ver, wk, rng)
+        if rng is not None and prec == L.PREC_F32:
+            ent = next((e for e in rng[3] if e["cache"] is cache and e["key"] == key), None)
+            if ent is None:
+                ent = {"cache": cache, "key": key}
+                rng[3].append(ent)
+            ent.update(ptr=ptr, tver=w._version, dims=(cout, cin, kh, kw), mode=mode, wk=wk)
+            rng[4] = None                       # job table is rebuilt at the next batched re-pack
     return wk
 
 

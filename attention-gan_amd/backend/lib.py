@@ -31,6 +31,8 @@ _SIGNATURES = {
     "agan_version": (c_int, []),
     "agan_last_error": (c_char_p, []),
     "agan_packed_weight_bytes": (c_size_t, [c_int] * 6),
+    "agan_pack_job_blocks": (c_int, [c_int] * 5),
+    "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),

@@ -505,9 +505,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 // weight packing (OIHW -> [cls][K][Nld]) and gradient unpacking ([split][cls][K][Nld] -> OIHW)
 // ================================================================================================
 // AGAN_PACK_FWD is a plain [cout][K] -> [K][Nld] transpose: 32x32 LDS tiles, coalesced on both sides.
-__global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld) {
-    __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+__device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld, int bx, int by,
+                                              float (*tile)[33]) {
+    const int k0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -521,24 +521,29 @@ __global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __rest
         if (k < K && n < Nld) wk[(size_t)k * Nld + n] = tile[tx][ty + j * 8];
     }
 }
+__global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld) {
+    __shared__ float tile[32][33];
+    pack_fwd_tile(w, wk, cout, K, Nld, blockIdx.x, blockIdx.y, tile);
+}
 
 // dgrad packs: wk[cls][(co, tap')][ci] = w[co][ci][tap(cls, tap')] -- per output channel co a [cin][T] -> [T'][cin] shuffle.
 // One workgroup stages a 64-input-channel slab of one co (64*T contiguous floats) in LDS and writes rows of 64 contiguous ci.
 template <int MODE>
-__global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin,
-                                                               int kh, int kw, int Nld) {
-    __shared__ float sl[64 * 16 + 64];
+__device__ __forceinline__ void pack_dgrad_tile(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin, int kh, int kw, int Nld,
+                                                int co, int cblk, float* sl /* 64*16+64 floats */, bool zero_pad) {
     const int T = kh * kw;
-    const int co = blockIdx.x, c0 = blockIdx.y * 64;
+    const int c0 = cblk * 64;
     const int nc = min(64, cin - c0);
     const float* src = w + ((size_t)co * cin + c0) * T;
     for (int i = threadIdx.x; i < nc * T; i += 256) sl[(i / T) * (T + 1) + (i % T)] = src[i];   // +1 pad: column walks below
     __syncthreads();
+    // columns [cin, Nld) of this output channel's rows are padding; the batched path clears them itself (last channel block)
+    const int cend = (zero_pad && c0 + 64 >= cin) ? Nld - c0 : nc;
     if (MODE == AGAN_PACK_DGRAD_S1) {
         // K index = (co, r, s); source tap = flipped
         for (int i = threadIdx.x; i < T * 64; i += 256) {
             const int t = i / 64, c = i - t * 64;
-            if (c < nc) wk[((size_t)co * T + t) * Nld + c0 + c] = sl[c * (T + 1) + (T - 1 - t)];
+            if (c < cend) wk[((size_t)co * T + t) * Nld + c0 + c] = c < nc ? sl[c * (T + 1) + (T - 1 - t)] : 0.f;
         }
     } else {   // AGAN_PACK_DGRAD_4x4S2: 4 classes x (co, r, s in {0,1}); tap kh = ((py+1)&1) + 2r
         const int K = cout * 4;
@@ -546,9 +551,15 @@ __global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const float* __re
             const int q = i / 64, c = i - q * 64;
             const int cls = q >> 2, r = (q >> 1) & 1, sx = q & 1, py = cls >> 1, px = cls & 1;
             const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * sx;
-            if (c < nc) wk[((size_t)cls * K + co * 4 + r * 2 + sx) * Nld + c0 + c] = sl[c * 17 + th * 4 + tw];
+            if (c < cend) wk[((size_t)cls * K + co * 4 + r * 2 + sx) * Nld + c0 + c] = c < nc ? sl[c * 17 + th * 4 + tw] : 0.f;
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin,
+                                                               int kh, int kw, int Nld) {
+    __shared__ float sl[64 * 16 + 64];
+    pack_dgrad_tile<MODE>(w, wk, cout, cin, kh, kw, Nld, blockIdx.x, blockIdx.y, sl, false);
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wk, int mode,
@@ -560,6 +571,51 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const size_t t = e / Nld;
         const int k = (int)(t % K), cls = (int)(t / K);
         wk[e] = packed_weight_value(w, mode, cls, k, n, cout, cin, kh, kw);
+    }
+}
+
+// Every stale packed weight of one optimiser in ONE launch (agan_pack_weights): after an Adam step a module re-packs ~25-80
+// tensors, most of them a few KB -- as separate launches they cost 10 us each whatever their size.
+__host__ __device__ inline int pack_job_blocks(int mode, int cout, int cin, int kh, int kw) {
+    int ncls, K, N;
+    if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
+    const int Nld = ((N + 31) / 32 * 32);
+    if (mode == AGAN_PACK_FWD) return cdiv(K, 32) * (Nld / 32);
+    if ((mode == AGAN_PACK_DGRAD_S1 && kh * kw <= 16) || mode == AGAN_PACK_DGRAD_4x4S2) return cout * cdiv(cin, 64);
+    const size_t total = (size_t)ncls * K * Nld;
+    return (int)(total / 1024 < 1 ? 1 : (total / 1024 > 2048 ? 2048 : total / 1024));
+}
+
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const agan_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float buf[64 * 16 + 64];
+    __shared__ int which;
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < njobs; t += 256) {
+        const int lo = jobs[t].first_block, hi = t + 1 < njobs ? jobs[t + 1].first_block : 0x7fffffff;
+        if (b >= lo && b < hi) which = t;
+    }
+    __syncthreads();
+    const agan_pack_job j = jobs[which];
+    const int local = b - j.first_block;
+    float* wk = static_cast<float*>(j.wk);
+    int ncls, K, N;
+    pack_dims(j.mode, j.cout, j.cin, j.kh, j.kw, ncls, K, N);
+    const int Nld = ((N + 31) / 32 * 32);
+    if (j.mode == AGAN_PACK_FWD) {
+        const int kt = cdiv(K, 32);
+        pack_fwd_tile(j.w, wk, j.cout, K, Nld, local % kt, local / kt, reinterpret_cast<float (*)[33]>(buf));
+    } else if (j.mode == AGAN_PACK_DGRAD_S1 && j.kh * j.kw <= 16) {
+        pack_dgrad_tile<AGAN_PACK_DGRAD_S1>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % j.cout, local / j.cout, buf, true);
+    } else if (j.mode == AGAN_PACK_DGRAD_4x4S2) {
+        pack_dgrad_tile<AGAN_PACK_DGRAD_4x4S2>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % j.cout, local / j.cout, buf, true);
+    } else {
+        const int nb = pack_job_blocks(j.mode, j.cout, j.cin, j.kh, j.kw);
+        const size_t total = (size_t)ncls * K * Nld;
+        for (size_t e = (size_t)local * 256 + threadIdx.x; e < total; e += (size_t)nb * 256) {
+            const int n = (int)(e % Nld);
+            const size_t t = e / Nld;
+            wk[e] = packed_weight_value(j.w, j.mode, (int)(t / K), (int)(t % K), n, j.cout, j.cin, j.kh, j.kw);
+        }
     }
 }
 
@@ -613,8 +669,8 @@ extern "C" {
 size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec) {
     int ncls, K, N;
     if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
-    if (prec == AGAN_PREC_F32) return (size_t)ncls * K * agan_round_up(N, 32) * sizeof(float);
-    if (prec == AGAN_PREC_BF16X3) return (size_t)ncls * 2 * agan_round_up(N, 32) * agan_round_up(K, 32) * sizeof(unsigned short);
+    if (prec == AGAN_PREC_F32) return (size_t)ncls * K * ((N + 31) / 32 * 32) * sizeof(float);
+    if (prec == AGAN_PREC_BF16X3) return (size_t)ncls * 2 * ((N + 31) / 32 * 32) * agan_round_up(K, 32) * sizeof(unsigned short);
     return 0;
 }
 
@@ -628,7 +684,7 @@ int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int
     }
     float* wk = static_cast<float*>(wkv);
     AGAN_REQUIRE(pack_dims(mode, cout, cin, kh, kw, ncls, K, N) == 0, "pack_weight: mode %d does not take %dx%d", mode, kh, kw);
-    const int Nld = agan_round_up(N, 32);
+    const int Nld = ((N + 31) / 32 * 32);
     const size_t total = (size_t)ncls * K * Nld;
     const int blocks = (int)std::min<size_t>(cdivz(total, 256), 8192);
     hipStream_t pst = as_stream(stream);
@@ -646,6 +702,15 @@ int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, wk, mode, cout, cin, kh, kw, K,
                        Nld, ncls);
     return check_launch("pack_weight");
+}
+
+int agan_pack_job_blocks(int mode, int cout, int cin, int kh, int kw) { return pack_job_blocks(mode, cout, cin, kh, kw); }
+
+int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, void* stream) {
+    AGAN_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "pack_weights: empty job list");
+    AGAN_REQUIRE(prec == AGAN_PREC_F32, "pack_weights: the batched path packs fp32 layouts only (precision mode %d)", prec);
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), jobs, njobs);
+    return check_launch("pack_weights");
 }
 
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {

@@ -139,7 +139,7 @@ __device__ inline float packed_weight_value(const float* __restrict__ w, int mod
     return v;
 }
 
-inline int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, int& N) {
+__host__ __device__ inline int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, int& N) {
     switch (mode) {
         case AGAN_PACK_FWD: ncls = 1; K = cin * kh * kw; N = cout; return 0;
         case AGAN_PACK_DGRAD_S1: ncls = 1; K = cout * kh * kw; N = cin; return 0;

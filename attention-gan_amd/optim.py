@@ -46,6 +46,12 @@ class FlatAdam:
         # captured HIP graph keeps counting on replay; step_count mirrors it on the host for state_dict()
         self.step_state = torch.zeros(4, dtype=torch.int32, device=dev)
 
+    def __del__(self):
+        try:
+            HF.unregister_flat(self.flat)
+        except Exception:      # interpreter shutdown
+            pass
+
     # -- torch.optim-like surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Zero the flat gradient buffer and drop the per-parameter .grad references: the backward kernels write each

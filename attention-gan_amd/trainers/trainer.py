@@ -261,6 +261,7 @@ class GanTrainStep(ModelTrainer):
                 self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        HF.build_pack_tables()                             # the batched re-pack's job tables: host work, not capturable
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 agan = importlib.import_module("attention-gan_amd")
 HF = importlib.import_module("attention-gan_amd.backend.functional")
+L = importlib.import_module("attention-gan_amd.backend.lib")
 LAY = importlib.import_module("attention-gan_amd.utilities.layers")
 GEN = importlib.import_module("attention-gan_amd.networks.generator")
 GSUB = importlib.import_module("attention-gan_amd.networks.generator_submodules")
@@ -283,6 +284,34 @@ def test_discriminators_vs_golden(res):
     assert_close(x.grad, g["g_x"], RTOL, "g_x")
     check_param_grads(D, g, RTOL)
     check_running(D, g)
+
+
+def test_batched_pack_equals_single_packs():
+    """agan_pack_weights (one launch for a whole module) must write exactly what agan_pack_weight writes per tensor, for every
+    layout mode, ragged channel counts and the zeroed padding columns (the batched buffers start as NaN)."""
+    lib = L.load()
+    rng = torch.Generator().manual_seed(21)
+    cases = [(L.PACK_FWD, 64, 3, 4), (L.PACK_FWD, 100, 37, 3), (L.PACK_FWD, 1, 128, 1), (L.PACK_DGRAD_S1, 48, 100, 3),
+             (L.PACK_DGRAD_S1, 3, 32, 3), (L.PACK_DGRAD_4x4S2, 64, 3, 4), (L.PACK_DGRAD_4x4S2, 96, 70, 4),
+             (L.PACK_UP_FWD, 40, 24, 3), (L.PACK_UP_DGRAD, 40, 24, 3)]
+    jobs = np.zeros(len(cases), dtype=HF._PACK_JOB_DTYPE)
+    ws, singles, batched, first = [], [], [], 0
+    for i, (mode, cout, cin, k) in enumerate(cases):
+        w = torch.randn(cout, cin, k, k, generator=rng).to(DEV)
+        n = lib.agan_packed_weight_bytes(mode, cout, cin, k, k, L.PREC_F32)
+        a = torch.zeros(n // 4, dtype=torch.float32, device=DEV)
+        b = torch.full((n // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        L.call("agan_pack_weight", HF._p(w), HF._p(a), mode, cout, cin, k, k, L.PREC_F32, HF._stream())
+        jobs[i] = (w.data_ptr(), b.data_ptr(), mode, cout, cin, k, k, first)
+        nb = lib.agan_pack_job_blocks(mode, cout, cin, k, k)
+        assert nb > 0
+        first += nb
+        ws.append(w); singles.append(a); batched.append(b)
+    table = torch.from_numpy(jobs.view(np.uint8).copy()).to(DEV)
+    L.call("agan_pack_weights", HF._p(table), len(cases), first, L.PREC_F32, HF._stream())
+    torch.cuda.synchronize()
+    for (mode, cout, cin, k), a, b in zip(cases, singles, batched):
+        assert torch.equal(a, b), f"mode {mode} cout {cout} cin {cin} k {k}"
 
 
 # ------------------------------------------------------------------------------------------------ losses

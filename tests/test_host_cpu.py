@@ -238,3 +238,27 @@ def test_batch_wire_format(tmp_path):
     words, lengths, cids, i64, i128, i256 = got[0]
     assert lengths.tolist() == [2, 6, 6, 2] and words.shape == (4, 6)
     assert float(i256.min()) >= -1.0 and float(i256.max()) <= 1.0 and i64.shape == (4, 3, 64, 64)
+
+
+def test_flat_buffer_epochs_are_per_buffer_and_survive_recycling():
+    """packed-weight caches follow the Adam steps of THEIR flat buffer (functional.register_flat): ranges are looked up by
+    address, an overlapping re-registration (recycled memory) drops the old range and starts above every epoch handed out."""
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    saved = list(HF._FLAT_RANGES)
+    try:
+        HF._FLAT_RANGES[:] = []
+        a, b = torch.zeros(100), torch.zeros(50)
+        HF.register_flat(a)
+        HF.register_flat(b)
+        ra, rb = HF._flat_range(a.data_ptr() + 40), HF._flat_range(b.data_ptr())
+        assert ra is not None and rb is not None and ra is not rb
+        assert HF._flat_range(a.data_ptr() + 400) is not ra            # one past the end
+        ra[2] += 5                                                    # five optimiser steps on a
+        assert rb[2] != ra[2]
+        HF.register_flat(a[10:60])                                    # same memory handed out again under another base
+        rn = HF._flat_range(a.data_ptr() + 44)
+        assert rn is not ra and rn[2] > ra[2] and ra not in HF._FLAT_RANGES
+        HF.unregister_flat(b)
+        assert HF._flat_range(b.data_ptr()) is None
+    finally:
+        HF._FLAT_RANGES[:] = saved
