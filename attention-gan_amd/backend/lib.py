@@ -31,6 +31,10 @@ _SIGNATURES = {
     "agan_version": (c_int, []),
     "agan_last_error": (c_char_p, []),
     "agan_packed_weight_bytes": (c_size_t, [c_int] * 6),
+    "agan_timer_create": (c_int, [_P]),
+    "agan_timer_destroy": (c_int, [_P]),
+    "agan_timer_arm": (c_int, [_P, _P]),
+    "agan_timer_elapsed_ms": (c_int, [_P, _P, _P]),
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

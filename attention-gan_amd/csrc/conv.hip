@@ -661,10 +661,46 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 
 }  // namespace
 
+// ---- measurement hook (bench.py roofline): one-shot HIP event pair recorded on the launch stream right around the NEXT
+// main conv kernel (gather or weight gradient), excluding the slab-sum / unpack passes that follow a split launch
+static thread_local hipEvent_t g_timer_start = nullptr, g_timer_stop = nullptr;
+static inline void timer_begin(hipStream_t st) {
+    if (g_timer_start) (void)hipEventRecord(g_timer_start, st);
+}
+static inline void timer_end(hipStream_t st) {
+    if (g_timer_stop) (void)hipEventRecord(g_timer_stop, st);
+    g_timer_start = g_timer_stop = nullptr;
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
 extern "C" {
+
+int agan_timer_create(void** event) {
+    AGAN_REQUIRE(event != nullptr, "timer_create: null pointer");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+        set_error("timer_create: hipEventCreate failed");
+        return AGAN_ELAUNCH;
+    }
+    *event = e;
+    return AGAN_OK;
+}
+int agan_timer_destroy(void* event) { return (event && hipEventDestroy(static_cast<hipEvent_t>(event)) != hipSuccess) ? AGAN_ELAUNCH : AGAN_OK; }
+int agan_timer_arm(void* start, void* stop) {
+    g_timer_start = static_cast<hipEvent_t>(start);
+    g_timer_stop = static_cast<hipEvent_t>(stop);
+    return AGAN_OK;
+}
+int agan_timer_elapsed_ms(void* start, void* stop, float* ms) {
+    AGAN_REQUIRE(start && stop && ms, "timer_elapsed_ms: null pointer");
+    if (hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) != hipSuccess) {
+        set_error("timer_elapsed_ms: events not complete");
+        return AGAN_ELAUNCH;
+    }
+    return AGAN_OK;
+}
 
 size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec) {
     int ncls, K, N;
@@ -745,7 +781,9 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     const Geom g = make_geom(gg);
     hipStream_t st = as_stream(stream);
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {
+        timer_begin(st);
         launch_gather_small_n(in, wk, bias, out, g, st);
+        timer_end(st);
         return check_launch("conv_gather/small_n");
     }
     const GatherPlan p = plan_gather(g, prec);
@@ -754,10 +792,12 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
         return AGAN_EWORKSPACE;
     }
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
+    timer_begin(st);
     if (prec == AGAN_PREC_BF16X3) launch_gather_bf16x3(in, wkv, bias, dst, ktab, g, p, st);
     else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
     else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, st);
     else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, st);
+    timer_end(st);
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
@@ -797,7 +837,9 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
             return AGAN_EWORKSPACE;
         }
         float* part = static_cast<float*>(ws);
+        timer_begin(st);
         launch_wgrad_small_n(x, dy, part, g, sp, st);
+        timer_end(st);
         const size_t n = (size_t)g.Cout * g.K;
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, part, sp.nchunk,
                            n, sp.slab, (const float*)nullptr, 1, 1, dw, accumulate);
@@ -819,11 +861,13 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     float* part = via_sum ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
 #define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab, acc_in_kernel)
+    timer_begin(st);
     if (prec == AGAN_PREC_BF16X3) launch_wgrad_bf16x3(x, dy, part, ktab, g, p, st);
     else if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
     else if (p.bi == 128) AGAN_WG(128, 64);
     else if (p.bj == 128) AGAN_WG(64, 128);
     else AGAN_WG(64, 64);
+    timer_end(st);
 #undef AGAN_WG
     if (int e = check_launch("conv_wgrad")) return e;
     const size_t n = (size_t)p.ncls * g.Cout * g.K;

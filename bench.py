@@ -12,6 +12,7 @@ all-reduced over RCCL.  Inputs are synthetic and already resident in HBM when th
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -45,11 +46,21 @@ def algorithmic_conv_flops(kind, B, Cin, H, W, Cout, k):
 
 
 class ConvTimer:
-    """HIP-event pairs around every conv-engine launch (the events go on torch's current stream, which is the stream the
-    kernels are enqueued on); durations are read after the timed region has been synchronised."""
+    """HIP-event pairs recorded by the library itself on the launch stream, immediately around the main kernel of every
+    conv-engine call (include/agan.h: agan_timer_arm) -- the slab-sum pass a split launch appends is outside the pair, so the
+    per-kernel averages here are the ones `rocprofv3 --kernel-trace --stats` reports for the same kernels.  Durations are read
+    after the instrumented region has been synchronised."""
 
-    def __init__(self, mode="f32"):
-        self.records, self.keys, self.enabled, self._open, self.mode = [], [], False, None, mode
+    def __init__(self, lib, mode="f32"):
+        self.lib, self.mode = lib, mode
+        self.records, self.keys, self.enabled, self._pool = [], [], False, []
+
+    def _event(self):
+        if self._pool:
+            return self._pool.pop()
+        e = ctypes.c_void_p()
+        self.lib.call("agan_timer_create", ctypes.byref(e))
+        return e
 
     def begin(self, kind, phase, g):
         if not self.enabled:
@@ -60,29 +71,35 @@ class ConvTimer:
         # the folded kernels (fwd: 4 classes x 2x2 taps; dgrad: 4x4 s2; wgrad: 4 classes) execute 4/9 of that.
         algorithmic = executed * (9.0 / 4.0) if kind == "up" else executed
         tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
+        if g.Cout <= 4:
+            tile = "small_n"
         name = f"conv_wgrad_{self.mode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
         # algorithmic HBM bytes of this call: gathered tensor + produced tensor + weights, each moved once (fp32)
         nbytes = 4.0 * (g.B * g.Cin * g.IH * g.IW + g.B * g.Cout * g.OH * g.OW + g.Cout * K * (g.OS * g.OS))
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self._key = f"{phase:5s} {kind:4s} B{g.B} {g.Cin:4d}x{g.IH:<3d} -> {g.Cout:4d}x{g.OH:<3d} taps {g.R}x{g.S} cls {g.OS * g.OS}"
-        self._open = (name, algorithmic, executed, nbytes, e0)
+        e0, e1 = self._event(), self._event()
+        self.lib.call("agan_timer_arm", e0, e1)
+        self.records.append((name, algorithmic, executed, nbytes, e0, e1))
+        self.keys.append(f"{phase:5s} {kind:4s} B{g.B} {g.Cin:4d}x{g.IH:<3d} -> {g.Cout:4d}x{g.OH:<3d} taps {g.R}x{g.S} cls {g.OS * g.OS}")
 
     def end(self):
-        if self._open is None:
-            return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        self.records.append(self._open + (e1,))
-        self.keys.append(self._key)
-        self._open = None
+        pass
+
+    def _ms(self, e0, e1):
+        ms = ctypes.c_float()
+        self.lib.call("agan_timer_elapsed_ms", e0, e1, ctypes.byref(ms))
+        return ms.value
+
+    def clear(self):
+        for rec in self.records:
+            self._pool += [rec[4], rec[5]]
+        self.records, self.keys = [], []
 
     def layer_table(self, steps):
         """per (phase, layer shape): launches and ms per step, executed TFLOP/s -- the list the next optimisation is read from"""
         by = {}
         for key, (name, fa, fe, nb, e0, e1) in zip(self.keys, self.records):
             d = by.setdefault(key, [0, 0.0, 0.0])
-            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fe
+            d[0] += 1; d[1] += self._ms(e0, e1); d[2] += fe
         rows = sorted(by.items(), key=lambda kv: -kv[1][1])
         out = [f"{'phase kind shape':58s} {'n/step':>6s} {'ms/step':>8s} {'exec TF/s':>9s}"]
         for key, (n, ms, fe) in rows:
@@ -94,7 +111,7 @@ class ConvTimer:
         by = {}
         for name, fa, fe, nb, e0, e1 in self.records:
             d = by.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
-            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fa; d[3] += fe; d[4] += nb
+            d[0] += 1; d[1] += self._ms(e0, e1); d[2] += fa; d[3] += fe; d[4] += nb
         return by
 
 
@@ -194,7 +211,7 @@ def main():
     HF.set_precision(LIB.PREC_F32 if args.precision == "f32" else LIB.PREC_BF16X3)
     step = build(dev, args.batch, HF, args.image_encoder)
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
-    timer = ConvTimer(args.precision)
+    timer = ConvTimer(importlib.import_module("attention-gan_amd.backend.lib"), args.precision)
     HF.set_launch_observer(timer)
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
@@ -234,16 +251,16 @@ def main():
     ROOF_STEPS = 2
     overlap = step.overlap_discriminators, step.overlap_weight_gradients
     step.overlap_discriminators = step.overlap_weight_gradients = False
-    timer.records.clear()
-    timer.keys.clear()
+    timer.clear()
     timer.enabled = True
     for _ in range(ROOF_STEPS):
         step.step(words, sent, lens_dev if use_graph else lens, None, reals)
     torch.cuda.synchronize()
     timer.enabled = False
     step.overlap_discriminators, step.overlap_weight_gradients = overlap
-    roofline_timing = (f"HIP events (on the launch stream) around every conv-engine launch in {ROOF_STEPS} single-stream eager steps run "
-                       "right after the timed region; the timed region itself overlaps streams / replays a HIP graph")
+    roofline_timing = ("HIP events recorded by the library on the launch stream immediately around each main conv kernel "
+                       f"(agan_timer_arm), over {ROOF_STEPS} single-stream eager steps run right after the timed region; the timed "
+                       "region itself overlaps streams / replays a HIP graph")
     if rank == 0 and args.layer_table:
         with open(args.layer_table, "w") as f:
             f.write(timer.layer_table(ROOF_STEPS) + "\n")

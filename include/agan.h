@@ -214,7 +214,16 @@ int agan_reparam_bwd(const float* logvar, const float* eps, const float* dc, flo
 int agan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int32_t* step_state, double lr,
                    double beta1, double beta2, double eps, float grad_scale, void* stream);
 
-/* utility used by the host: out = sum of nsplit slabs of n floats (+bias per channel if given) */
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py `roofline`): agan_timer_arm(start, stop) makes the NEXT agan_conv_gather / agan_conv_wgrad call on
+ * this thread record the two HIP events on its launch stream immediately around its main MFMA (or small-N) kernel -- not
+ * around the slab-sum / unpack passes a split launch appends.  One-shot; events come from agan_timer_create.
+ * ---------------------------------------------------------------------------------------------- */
+int agan_timer_create(void** event);
+int agan_timer_destroy(void* event);
+int agan_timer_arm(void* start, void* stop);
+int agan_timer_elapsed_ms(void* start, void* stop, float* ms);
+
 static inline int agan_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 #ifdef __cplusplus
