@@ -196,10 +196,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box (the real multi-GPU run uses neither): AGAN_BENCH_BACKEND=gloo and
+    # AGAN_BENCH_ONE_DEVICE=1 put every rank on cuda:0 and exchange gradients over gloo, so the whole N>1 control flow
+    # (bucket hooks, barriers, max-over-ranks timing, rank-0 report) runs on real kernels
+    backend = os.environ.get("AGAN_BENCH_BACKEND", "nccl")
+    if os.environ.get("AGAN_BENCH_ONE_DEVICE") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
