@@ -187,7 +187,8 @@ def main():
                     help="frozen DAMSM image encoder plug-in: 'standin' = contract-only stub (SURVEY §8d prices the hot path without "
                          "the third-party trunk); 'inception' = Inception-v3-shaped trunk on stock MIOpen convs, random weights")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the whole step as one captured HIP graph (auto: on for 1 GPU, off under torch.distributed)")
+                    help="launch mode of the step: captured HIP graph replay or eager (auto: at 1 GPU probe both in the untimed warm-up and keep "
+                         "the faster; eager under torch.distributed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented steps to this file")
@@ -223,16 +224,35 @@ def main():
     timer = ConvTimer(importlib.import_module("attention-gan_amd.backend.lib"), args.precision)
     HF.set_launch_observer(timer)
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
-    if use_graph:
-        lens_dev = torch.tensor(lens, dtype=torch.int64, device=dev)
-        graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
+    # caption lengths live on the device like the rest of the batch (inputs are resident in HBM when the timed region starts):
+    # a host list would cost two small blocking H2D copies per step, which stall the eager launch pipeline by ~4 ms
+    lens_dev = torch.tensor(lens, dtype=torch.int64, device=dev)
 
-        def one_step():
-            return graphed.replay()
-    else:
-        def one_step():
-            return step.step(words, sent, lens, None, reals)
+    def eager_step():
+        return step.step(words, sent, lens_dev, None, reals)
+
+    # Launch mode.  Eager: ~1000 launches per step from Python (~14 ms of host time, hidden behind ~29 ms of GPU time on an
+    # unloaded host).  Graph: the whole step captured once and replayed (no host work, but hipGraphLaunch adds per-node cost:
+    # measured 813 vs 830 images/s on an idle box).  `auto` at N=1 captures the graph, times a few UNTIMED steps of each
+    # and keeps the faster one for the measured region; under torch.distributed the step stays eager (RCCL is not captured).
+    use_graph = args.graph == "on"
+    graphed = None
+    if world == 1 and args.graph in ("on", "auto"):
+        graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
+    if world == 1 and args.graph == "auto":
+        def probe(fn, n=4):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        t_eager, t_graph = probe(eager_step), probe(graphed.replay)
+        use_graph = t_graph < t_eager
+        print(f"[bench] launch probe: eager {t_eager * 1e3:.2f} ms/step, graph replay {t_graph * 1e3:.2f} ms/step -> "
+              f"{'graph' if use_graph else 'eager'}", file=sys.stderr, flush=True)
+    one_step = graphed.replay if use_graph else eager_step
 
     for _ in range(args.warmup):
         one_step()
@@ -263,7 +283,7 @@ def main():
     timer.clear()
     timer.enabled = True
     for _ in range(ROOF_STEPS):
-        step.step(words, sent, lens_dev if use_graph else lens, None, reals)
+        step.step(words, sent, lens_dev, None, reals)
     torch.cuda.synchronize()
     timer.enabled = False
     step.overlap_discriminators, step.overlap_weight_gradients = overlap
