@@ -156,6 +156,11 @@ class GanTrainStep(ModelTrainer):
 
     def step(self, word_embs: Tensor, sent_embs: Tensor, lengths, class_ids, real_imgs: Sequence[Tensor],
              noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        if word_embs.is_cuda and not (isinstance(lengths, Tensor) and lengths.is_cuda):
+            # host-side caption lengths (the reference's DataLoader hands over a list / CPU tensor): ONE pinned, non-blocking
+            # copy up front -- a blocking H2D copy in the middle of the step drains the launch pipeline (~4 ms per step)
+            host = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1)
+            lengths = host.pin_memory().to(word_embs.device, non_blocking=True)
         prev_side = HF.set_wgrad_side_stream(self.overlap_weight_gradients and word_embs.is_cuda)
         try:
             return self._step(word_embs, sent_embs, lengths, class_ids, real_imgs, noise, eps)
