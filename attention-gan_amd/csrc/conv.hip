@@ -505,60 +505,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __rest
 // weight packing (OIHW -> [cls][K][Nld]) and gradient unpacking ([split][cls][K][Nld] -> OIHW)
 // ================================================================================================
 // AGAN_PACK_FWD is a plain [cout][K] -> [K][Nld] transpose: 32x32 LDS tiles, coalesced on both sides.
+// 64x64 tiles, 16 independent loads per thread in flight before the first LDS store (these passes are pure HBM streaming)
 __device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld, int bx, int by,
-                                              float (*tile)[33]) {
-    const int k0 = bx * 32, n0 = by * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+                                              float (*tile)[65]) {
+    const int k0 = bx * 64, n0 = by * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + ty + j * 8, k = k0 + tx;
-        tile[ty + j * 8][tx] = (n < cout && k < K) ? w[(size_t)n * K + k] : 0.f;
+    for (int j = 0; j < 16; ++j) {
+        const int n = n0 + ty + j * 4, k = k0 + tx;
+        v[j] = (n < cout && k < K) ? w[(size_t)n * K + k] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[ty + j * 4][tx] = v[j];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + ty + j * 8, n = n0 + tx;
-        if (k < K && n < Nld) wk[(size_t)k * Nld + n] = tile[tx][ty + j * 8];
+    for (int j = 0; j < 16; ++j) {
+        const int k = k0 + ty + j * 4, n = n0 + tx;
+        if (k < K && n < Nld) wk[(size_t)k * Nld + n] = tile[tx][ty + j * 4];
     }
 }
 __global__ __launch_bounds__(256) void pack_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int K, int Nld) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     pack_fwd_tile(w, wk, cout, K, Nld, blockIdx.x, blockIdx.y, tile);
 }
 
 // dgrad packs: wk[cls][(co, tap')][ci] = w[co][ci][tap(cls, tap')] -- per output channel co a [cin][T] -> [T'][cin] shuffle.
 // One workgroup stages a 64-input-channel slab of one co (64*T contiguous floats) in LDS and writes rows of 64 contiguous ci.
+constexpr int kPackCo = 4;                  // output channels per workgroup of the dgrad packs (loads of all four in flight)
+constexpr int kPackSlab = 64 * 16 + 64;     // one (co, 64 ci) slab: 64 x T floats, rows padded by one
 template <int MODE>
 __device__ __forceinline__ void pack_dgrad_tile(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin, int kh, int kw, int Nld,
-                                                int co, int cblk, float* sl /* 64*16+64 floats */, bool zero_pad) {
+                                                int cog, int cblk, float* sl /* kPackCo * kPackSlab floats */, bool zero_pad) {
     const int T = kh * kw;
     const int c0 = cblk * 64;
     const int nc = min(64, cin - c0);
-    const float* src = w + ((size_t)co * cin + c0) * T;
-    for (int i = threadIdx.x; i < nc * T; i += 256) sl[(i / T) * (T + 1) + (i % T)] = src[i];   // +1 pad: column walks below
+#pragma unroll
+    for (int q = 0; q < kPackCo; ++q) {
+        const int co = cog * kPackCo + q;
+        if (co < cout) {
+            const float* src = w + ((size_t)co * cin + c0) * T;
+            for (int i = threadIdx.x; i < nc * T; i += 256) sl[q * kPackSlab + (i / T) * (T + 1) + (i % T)] = src[i];   // +1 pad: column walks below
+        }
+    }
     __syncthreads();
     // columns [cin, Nld) of this output channel's rows are padding; the batched path clears them itself (last channel block)
     const int cend = (zero_pad && c0 + 64 >= cin) ? Nld - c0 : nc;
-    if (MODE == AGAN_PACK_DGRAD_S1) {
-        // K index = (co, r, s); source tap = flipped
-        for (int i = threadIdx.x; i < T * 64; i += 256) {
-            const int t = i / 64, c = i - t * 64;
-            if (c < cend) wk[((size_t)co * T + t) * Nld + c0 + c] = c < nc ? sl[c * (T + 1) + (T - 1 - t)] : 0.f;
-        }
-    } else {   // AGAN_PACK_DGRAD_4x4S2: 4 classes x (co, r, s in {0,1}); tap kh = ((py+1)&1) + 2r
-        const int K = cout * 4;
-        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-            const int q = i / 64, c = i - q * 64;
-            const int cls = q >> 2, r = (q >> 1) & 1, sx = q & 1, py = cls >> 1, px = cls & 1;
-            const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * sx;
-            if (c < cend) wk[((size_t)cls * K + co * 4 + r * 2 + sx) * Nld + c0 + c] = c < nc ? sl[c * 17 + th * 4 + tw] : 0.f;
+#pragma unroll
+    for (int q = 0; q < kPackCo; ++q) {
+        const int co = cog * kPackCo + q;
+        if (co >= cout) break;
+        const float* s1 = sl + q * kPackSlab;
+        if (MODE == AGAN_PACK_DGRAD_S1) {
+            // K index = (co, r, s); source tap = flipped
+            for (int i = threadIdx.x; i < T * 64; i += 256) {
+                const int t = i / 64, c = i - t * 64;
+                if (c < cend) wk[((size_t)co * T + t) * Nld + c0 + c] = c < nc ? s1[c * (T + 1) + (T - 1 - t)] : 0.f;
+            }
+        } else {   // AGAN_PACK_DGRAD_4x4S2: 4 classes x (co, r, s in {0,1}); tap kh = ((py+1)&1) + 2r
+            const int K = cout * 4;
+            for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+                const int qq = i / 64, c = i - qq * 64;
+                const int cls = qq >> 2, r = (qq >> 1) & 1, sx = qq & 1, py = cls >> 1, px = cls & 1;
+                const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * sx;
+                if (c < cend) wk[((size_t)cls * K + co * 4 + r * 2 + sx) * Nld + c0 + c] = c < nc ? s1[c * 17 + th * 4 + tw] : 0.f;
+            }
         }
     }
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const float* __restrict__ w, float* __restrict__ wk, int cout, int cin,
                                                                int kh, int kw, int Nld) {
-    __shared__ float sl[64 * 16 + 64];
+    __shared__ float sl[kPackCo * kPackSlab];
     pack_dgrad_tile<MODE>(w, wk, cout, cin, kh, kw, Nld, blockIdx.x, blockIdx.y, sl, false);
 }
 
@@ -580,14 +598,14 @@ __host__ __device__ inline int pack_job_blocks(int mode, int cout, int cin, int 
     int ncls, K, N;
     if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
     const int Nld = ((N + 31) / 32 * 32);
-    if (mode == AGAN_PACK_FWD) return cdiv(K, 32) * (Nld / 32);
-    if ((mode == AGAN_PACK_DGRAD_S1 && kh * kw <= 16) || mode == AGAN_PACK_DGRAD_4x4S2) return cout * cdiv(cin, 64);
+    if (mode == AGAN_PACK_FWD) return cdiv(K, 64) * cdiv(Nld, 64);
+    if ((mode == AGAN_PACK_DGRAD_S1 && kh * kw <= 16) || mode == AGAN_PACK_DGRAD_4x4S2) return cdiv(cout, kPackCo) * cdiv(cin, 64);
     const size_t total = (size_t)ncls * K * Nld;
     return (int)(total / 1024 < 1 ? 1 : (total / 1024 > 2048 ? 2048 : total / 1024));
 }
 
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const agan_pack_job* __restrict__ jobs, int njobs) {
-    __shared__ float buf[64 * 16 + 64];
+    __shared__ float buf[kPackCo * kPackSlab > 64 * 65 ? kPackCo * kPackSlab : 64 * 65];
     __shared__ int which;
     const int b = blockIdx.x;
     for (int t = threadIdx.x; t < njobs; t += 256) {
@@ -602,12 +620,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const agan_pack_job* __r
     pack_dims(j.mode, j.cout, j.cin, j.kh, j.kw, ncls, K, N);
     const int Nld = ((N + 31) / 32 * 32);
     if (j.mode == AGAN_PACK_FWD) {
-        const int kt = cdiv(K, 32);
-        pack_fwd_tile(j.w, wk, j.cout, K, Nld, local % kt, local / kt, reinterpret_cast<float (*)[33]>(buf));
+        const int kt = cdiv(K, 64);
+        pack_fwd_tile(j.w, wk, j.cout, K, Nld, local % kt, local / kt, reinterpret_cast<float (*)[65]>(buf));
     } else if (j.mode == AGAN_PACK_DGRAD_S1 && j.kh * j.kw <= 16) {
-        pack_dgrad_tile<AGAN_PACK_DGRAD_S1>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % j.cout, local / j.cout, buf, true);
+        const int cg = cdiv(j.cout, kPackCo);
+        pack_dgrad_tile<AGAN_PACK_DGRAD_S1>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % cg, local / cg, buf, true);
     } else if (j.mode == AGAN_PACK_DGRAD_4x4S2) {
-        pack_dgrad_tile<AGAN_PACK_DGRAD_4x4S2>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % j.cout, local / j.cout, buf, true);
+        const int cg = cdiv(j.cout, kPackCo);
+        pack_dgrad_tile<AGAN_PACK_DGRAD_4x4S2>(j.w, wk, j.cout, j.cin, j.kh, j.kw, Nld, local % cg, local / cg, buf, true);
     } else {
         const int nb = pack_job_blocks(j.mode, j.cout, j.cin, j.kh, j.kw);
         const size_t total = (size_t)ncls * K * Nld;
@@ -725,12 +745,12 @@ int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int
     const int blocks = (int)std::min<size_t>(cdivz(total, 256), 8192);
     hipStream_t pst = as_stream(stream);
     if (mode == AGAN_PACK_FWD) {
-        hipLaunchKernelGGL(pack_fwd_tiled_kernel, dim3(cdiv(K, 32), Nld / 32), dim3(256), 0, pst, w, wk, cout, K, Nld);
+        hipLaunchKernelGGL(pack_fwd_tiled_kernel, dim3(cdiv(K, 64), cdiv(Nld, 64)), dim3(256), 0, pst, w, wk, cout, K, Nld);
         return check_launch("pack_weight/fwd");
     }
     if ((mode == AGAN_PACK_DGRAD_S1 && kh * kw <= 16) || mode == AGAN_PACK_DGRAD_4x4S2) {
         if (Nld != cin) (void)hipMemsetAsync(wk, 0, total * sizeof(float), pst);      // zero the N padding columns
-        dim3 grid(cout, cdiv(cin, 64));
+        dim3 grid(cdiv(cout, kPackCo), cdiv(cin, 64));
         if (mode == AGAN_PACK_DGRAD_S1) hipLaunchKernelGGL((pack_dgrad_tiled_kernel<AGAN_PACK_DGRAD_S1>), grid, dim3(256), 0, pst, w, wk, cout, cin, kh, kw, Nld);
         else hipLaunchKernelGGL((pack_dgrad_tiled_kernel<AGAN_PACK_DGRAD_4x4S2>), grid, dim3(256), 0, pst, w, wk, cout, cin, kh, kw, Nld);
         return check_launch("pack_weight/dgrad");
