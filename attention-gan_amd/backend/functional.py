@@ -268,7 +268,8 @@ def set_launch_observer(obs) -> None:
     _OBSERVER[0] = obs
 
 
-def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "") -> None:
+def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "",
+            act: int = 0) -> None:
     lib = L.load()
     nbytes = lib.agan_conv_gather_ws_bytes(byref(g), _PRECISION[0])
     ws, wsp = _ws(nbytes, x)
@@ -276,7 +277,7 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
     obs = _OBSERVER[0]
     if obs is not None:
         obs.begin(kind, phase, g)
-    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], wsp, nbytes, _stream())
+    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], act, wsp, nbytes, _stream())
     if obs is not None:
         obs.end()
 
@@ -338,7 +339,7 @@ def join_side_stream() -> None:
 
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst, act: int = 0):
         x = _dev(x, "conv input")
         w = _dev(weight.detach(), "conv weight")
         B, Cin, H, W = x.shape
@@ -348,16 +349,24 @@ class _ConvFn(Function):
         gf, pf, gd, pd, (OH, OW) = conv_geoms(kind, B, Cin, H, W, Cout, kh)
         out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
-        _gather(x, packed_weight(w, pf, cache), b, gf, out, kind, "fwd")
-        ctx.save_for_backward(x, w)
-        ctx.kind, ctx.has_bias, ctx.cache, ctx.wdst, ctx.bdst = kind, bias is not None, cache, wdst, bdst
+        _gather(x, packed_weight(w, pf, cache), b, gf, out, kind, "fwd", act)
+        if act == L.ACT_NONE:
+            ctx.save_for_backward(x, w)
+        else:                       # fused LeakyReLU: the backward needs the sign of the output
+            ctx.save_for_backward(x, w, out)
+        ctx.kind, ctx.has_bias, ctx.cache, ctx.wdst, ctx.bdst, ctx.act = kind, bias is not None, cache, wdst, bdst, act
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy: Tensor):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         dy = _dev(dy, "conv grad")
+        if ctx.act != L.ACT_NONE:
+            out = ctx.saved_tensors[2]
+            dz = torch.empty_like(dy)
+            L.call("agan_act_bwd", _p(out), _p(dy), _p(dz), out.numel(), ctx.act, _stream())
+            dy = dz
         B, Cin, H, W = x.shape
         Cout, _, kh, kw = w.shape
         gf, pf, gd, pd, _ = conv_geoms(ctx.kind, B, Cin, H, W, Cout, kh)
@@ -389,14 +398,20 @@ class _ConvFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_fuses_activation(act: int, cout: int) -> bool:
+    """can conv2d apply `act` in its epilogue? (LeakyReLU on the fp32 MFMA path; include/agan.h: agan_conv_gather)"""
+    return act == L.ACT_LRELU and _PRECISION[0] == L.PREC_F32 and cout > 4
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None,
-           wdst=None, bdst=None) -> Tensor:
+           wdst=None, bdst=None, act: int = 0) -> Tensor:
     """conv forward with autograd (dgrad + wgrad kernels).  kind: 'same' | 'down' | 'up' (conv_geoms).
-    wdst / bdst: optional flat-gradient destinations of weight / bias (grad_dst(param))."""
-    return _ConvFn.apply(x, weight, bias, kind, cache, wdst, bdst)
+    wdst / bdst: optional flat-gradient destinations of weight / bias (grad_dst(param)).
+    act: ACT_LRELU applies the activation in the conv epilogue (see conv_fuses_activation)."""
+    return _ConvFn.apply(x, weight, bias, kind, cache, wdst, bdst, act)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Optional[dict] = None, wdst=None, bdst=None) -> Tensor:

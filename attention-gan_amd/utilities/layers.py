@@ -35,9 +35,10 @@ class HipConv2d(nn.Conv2d):
         self.kind = kind
         self._packed = {}        # packed-weight cache (layout copies for the kernels; not part of state_dict)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, act: int = L.ACT_NONE) -> Tensor:
+        """`act` (only where HF.conv_fuses_activation allows it) applies the following activation in the conv epilogue."""
         return HF.conv2d(x, self.weight, self.bias, self.kind, self._packed, HF.grad_dst(self.weight),
-                         HF.grad_dst(self.bias) if self.bias is not None else None)
+                         HF.grad_dst(self.bias) if self.bias is not None else None, act)
 
 
 class HipLinear(nn.Linear):
@@ -106,7 +107,11 @@ class FusedChain(nn.Module):
     def run(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         last = len(self._stages) - 1
         for i, st in enumerate(self._stages):
-            y = getattr(self, st.conv)(x)
+            conv = getattr(self, st.conv)
+            if st.bn is None and HF.conv_fuses_activation(st.act, conv.out_channels):
+                x = conv(x, st.act)                       # conv + LeakyReLU in one kernel (no BatchNorm in between)
+                continue
+            y = conv(x)
             if st.bn is not None:
                 x = getattr(self, st.bn).fused(y, st.act, residual if i == last else None)
             elif st.act != L.ACT_NONE:

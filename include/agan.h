@@ -95,7 +95,8 @@ int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, in
 
 /* conv forward / dgrad: replaces F.conv2d fwd+dgrad under Layers.conv3x3 / conv4x4 s2 / Upsample+conv3x3 /
  * nn.Linear (1x1 on a 1x1 image) -- utilities/layers.py:50-53,64-65,122,139-150; generator_submodules.py:36,152;
- * discriminators.py:15.   bias may be NULL. */
+ * discriminators.py:15.   bias may be NULL.  act: AGAN_ACT_NONE, or AGAN_ACT_LRELU to apply the LeakyReLU(0.2) that follows a
+ * conv without BatchNorm (layers.py:139-141, first stage of encode_image_by_16times) in the epilogue (fp32 MFMA path only). */
 /* Reduction-index table of a geometry (one int32 pair per k = (ci,r,s), padded): build it once per geometry with
  * agan_conv_ktable() into agan_conv_ktable_elems() int32s and pass it to every conv call of that geometry.  It lets the
  * kernels fetch the im2col offsets with scalar loads instead of decoding k with integer divisions. */
@@ -104,7 +105,7 @@ int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
 
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
 int agan_conv_gather(const float* in, const void* wk, const float* bias, float* out, const agan_conv_geom* g,
-                     const int32_t* ktable, int prec, void* ws, size_t ws_bytes, void* stream);
+                     const int32_t* ktable, int prec, int act, void* ws, size_t ws_bytes, void* stream);
 
 /* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.
  * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).

@@ -286,6 +286,29 @@ def test_discriminators_vs_golden(res):
     check_running(D, g)
 
 
+@pytest.mark.parametrize("kind,B,Cin,H,Cout,k", [("down", 3, 3, 32, 64, 4), ("same", 2, 512, 4, 64, 3), ("down", 2, 256, 8, 96, 4)])
+def test_conv_with_fused_leaky_relu_vs_torch(kind, B, Cin, H, Cout, k):
+    """LeakyReLU(0.2) applied in the conv epilogue (first stage of encode_image_by_16times, layers.py:139-141): forward and all
+    gradients against torch's conv + leaky_relu; the second and third shapes split K, so the slab-sum pass applies it."""
+    assert HF.conv_fuses_activation(L.ACT_LRELU, Cout)
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, H, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=gen) * 0.1
+    stride, pad = (1, 1) if kind == "same" else (2, 1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr, wr, br, stride=stride, padding=pad), 0.2)
+    gy = torch.randn(yr.shape, generator=gen)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = HF.conv2d(xd, wd, bd, kind, None, None, None, L.ACT_LRELU)
+    yd.backward(gy.to(DEV))
+    assert_close(yd, yr, TOL.tight, "y")
+    assert_close(xd.grad, xr.grad, RTOL, "dx")
+    assert_close(wd.grad, wr.grad, RTOL, "dw")
+    assert_close(bd.grad, br.grad, RTOL, "db")
+
+
 def test_batched_pack_equals_single_packs():
     """agan_pack_weights (one launch for a whole module) must write exactly what agan_pack_weight writes per tensor, for every
     layout mode, ragged channel counts and the zeroed padding columns (the batched buffers start as NaN)."""
