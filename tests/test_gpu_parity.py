@@ -309,6 +309,36 @@ def test_conv_with_fused_leaky_relu_vs_torch(kind, B, Cin, H, Cout, k):
     assert_close(bd.grad, br.grad, RTOL, "db")
 
 
+def test_measurement_hook_times_the_main_conv_kernel():
+    """agan_timer_arm: the next conv call records the event pair around its main kernel (bench.py's roofline timing).  One-shot:
+    a second call without re-arming leaves the events untouched."""
+    import ctypes
+    lib = L.load()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.call("agan_timer_create", ctypes.byref(e0))
+    L.call("agan_timer_create", ctypes.byref(e1))
+    x = torch.randn(4, 64, 64, 64, device=DEV)
+    w = torch.randn(128, 64, 3, 3, device=DEV) / 24
+    gf, pf, _, _, (OH, OW) = HF.conv_geoms("same", 4, 64, 64, 64, 128, 3)
+    y = torch.empty(4, 128, OH, OW, device=DEV)
+    wk = HF.packed_weight(w, pf)
+    HF._gather(x, wk, None, gf, y)                      # warm (tables)
+    L.call("agan_timer_arm", e0, e1)
+    HF._gather(x, wk, None, gf, y)
+    torch.cuda.synchronize()
+    ms = ctypes.c_float()
+    L.call("agan_timer_elapsed_ms", e0, e1, ctypes.byref(ms))
+    flops = 2.0 * 4 * 64 * 64 * 128 * 64 * 9
+    assert 0.0 < ms.value < 5.0 and flops / (ms.value * 1e-3) < 157.3e12 * 1.05        # a real duration, below the MFMA peak
+    first = ms.value
+    HF._gather(x, wk, None, gf, y)                      # not armed: events keep their timestamps
+    torch.cuda.synchronize()
+    L.call("agan_timer_elapsed_ms", e0, e1, ctypes.byref(ms))
+    assert ms.value == first
+    L.call("agan_timer_destroy", e0)
+    L.call("agan_timer_destroy", e1)
+
+
 def test_batched_pack_equals_single_packs():
     """agan_pack_weights (one launch for a whole module) must write exactly what agan_pack_weight writes per tensor, for every
     layout mode, ragged channel counts and the zeroed padding columns (the batched buffers start as NaN)."""
