@@ -424,31 +424,58 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Opti
 # --------------------------------------------------------------------------------------------------------------
 # BatchNorm (train mode) + activation
 # --------------------------------------------------------------------------------------------------------------
+# Batch groups: a discriminator update runs the real and the fake batch through the same weights.  The reference does two
+# forward passes (disc_loss.py:55-61), so every BatchNorm sees each batch on its own: batch statistics per pass, two running-
+# statistic updates in call order.  `with bn_groups(2)` lets one pass over the concatenated [real; fake] batch reproduce that:
+# each BatchNorm call treats the batch axis as `groups` consecutive sub-batches and runs its kernels per sub-batch (statistics,
+# running-stat update and normalisation in group order; the backward accumulates gamma/beta gradients over the groups).  The
+# convolutions in between simply see twice the pixels -- half the launches, better-filled tiles on the deep 4x4..16x16 layers.
+_BN_GROUPS = [1]
+
+
+@contextlib.contextmanager
+def bn_groups(groups: int):
+    old = _BN_GROUPS[0]
+    _BN_GROUPS[0] = int(groups)
+    try:
+        yield
+    finally:
+        _BN_GROUPS[0] = old
+
+
 class _BnActFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum, gdst, bdst):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum, gdst, bdst, groups):
         x = _dev(x, "bn input")
         shape = x.shape
         B, C = shape[0], shape[1]
         HW = x.numel() // (B * C)
+        if not training:
+            groups = 1
+        if B % groups:
+            raise L.AganError(f"BatchNorm: batch {B} does not split into {groups} groups")
+        Bg = B // groups
         g, b = _dev(gamma.detach(), "bn weight"), _dev(beta.detach(), "bn bias")
         lib = L.load()
         co = C // 2 if act == L.ACT_GLU else C
         out = torch.empty((B, co) + tuple(shape[2:]), dtype=torch.float32, device=x.device)
         res = _dev(residual, "bn residual") if residual is not None else None
         if training:
-            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
-            nbytes = lib.agan_bn_train_fwd_ws_bytes(B, C, HW)
+            nbytes = lib.agan_bn_train_fwd_ws_bytes(Bg, C, HW)
             ws, wsp = _ws(nbytes, x)
-            L.call("agan_bn_train_fwd", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
-                   _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, wsp, nbytes, _stream())
+            for k in range(groups):                           # same stream: the running-stat updates happen in group order
+                sl = slice(k * Bg, (k + 1) * Bg)
+                L.call("agan_bn_train_fwd", _p(x[sl]), _p(g), _p(b), _p(res[sl]) if res is not None else None, _p(out[sl]),
+                       _p(mean[k]), _p(invstd[k]), _p(running_mean), _p(running_var), _p(nbt), Bg, C, HW, float(eps),
+                       float(momentum), act, wsp, nbytes, _stream())
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
             L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
         ctx.save_for_backward(x, g, b, mean, invstd)
-        ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst = act, training, residual is not None, gdst, bdst
+        ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst, ctx.groups = act, training, residual is not None, gdst, bdst, groups
         return out
 
     @staticmethod
@@ -460,23 +487,29 @@ class _BnActFn(Function):
         dout = _dev(dout, "bn grad")
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
+        groups = ctx.groups
+        Bg = B // groups
         dx = torch.empty_like(x)
         dgbuf, gacc, dg = _grad_out(ctx.gdst, g.shape, x)
         dbbuf, bacc, db = _grad_out(ctx.bdst, b.shape, x)
         if gacc != bacc:
             raise L.AganError("BatchNorm weight/bias gradient destinations out of step")
-        nbytes = L.load().agan_bn_act_bwd_ws_bytes(B, C, HW)
+        nbytes = L.load().agan_bn_act_bwd_ws_bytes(Bg, C, HW)
         ws, wsp = _ws(nbytes, x)
-        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
-               ctx.act, gacc, wsp, nbytes, _stream())
+        for k in range(groups):                               # gamma/beta gradients: group 0 writes (or adds), the rest add
+            sl = slice(k * Bg, (k + 1) * Bg)
+            L.call("agan_bn_act_bwd", _p(x[sl]), _p(dout[sl]), _p(mean[k]), _p(invstd[k]), _p(g), _p(b), _p(dx[sl]), _p(dgbuf),
+                   _p(dbbuf), Bg, C, HW, ctx.act, gacc if k == 0 else 1, wsp, nbytes, _stream())
         dres = dout if ctx.has_res else None
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, nbt, training: bool, act: int, residual=None,
            eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+    """Train-mode BatchNorm + activation (+ residual).  Inside `with bn_groups(G)` the batch axis is G consecutive sub-batches,
+    each normalised with its own statistics (see bn_groups above)."""
     return _BnActFn.apply(x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum,
-                          grad_dst(gamma), grad_dst(beta))
+                          grad_dst(gamma), grad_dst(beta), _BN_GROUPS[0])
 
 
 class _ActFn(Function):

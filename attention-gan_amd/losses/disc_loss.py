@@ -20,9 +20,23 @@ class DiscLoss:
 
 
 class NonSaturatingDiscLoss(DiscLoss):
-    """-mean(log(D(x)+1e-8) + log(1-D(G(z))+1e-8)); the real batch goes through D first (disc_loss.py:55-61)."""
+    """-mean(log(D(x)+1e-8) + log(1-D(G(z))+1e-8)); the real batch goes through D first (disc_loss.py:55-61).
+
+    With a discriminator of this package the two passes are ONE pass over the concatenated [real; fake] batch inside
+    `functional.bn_groups(2)`: every BatchNorm still normalises each half with its own statistics and updates its running
+    statistics twice, real first -- the reference's results -- while every convolution runs once on twice the pixels (half
+    the launches; the deep 4x4..16x16 layers, M = 384 pixels per batch, fill their tiles twice as well).  `batch_pairs = False`
+    restores the two separate passes."""
+
+    batch_pairs = True
 
     def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
+        if (self.batch_pairs and getattr(discriminator, "supports_batch_groups", False) and discriminator.training
+                and fake_images.is_cuda and fake_images.shape == real_images.shape):
+            n = real_images.shape[0]
+            with HF.bn_groups(2):
+                score = discriminator(torch.cat([real_images, fake_images], dim=0))
+            return HF.ns_disc_loss(score[:n], score[n:])
         dx_score = discriminator(real_images)
         dg_score = discriminator(fake_images)
         return HF.ns_disc_loss(dx_score, dg_score)

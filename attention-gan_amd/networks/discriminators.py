@@ -27,6 +27,10 @@ class _LogitHead(nn.Module):
 
 
 class _Disc(nn.Module):
+    # every BatchNorm inside is a HipBatchNorm2d and nothing else couples samples of a batch, so a [real; fake] batch may go
+    # through in one pass under functional.bn_groups(2) (losses/disc_loss.py)
+    supports_batch_groups = True
+
     def _tail(self, x: Tensor) -> Tensor:
         return self.outlogits(x).view(-1)
 
