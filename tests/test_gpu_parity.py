@@ -309,6 +309,33 @@ def test_conv_with_fused_leaky_relu_vs_torch(kind, B, Cin, H, Cout, k):
     assert_close(bd.grad, br.grad, RTOL, "db")
 
 
+def test_paired_discriminator_pass_equals_two_passes():
+    """disc_loss.py:55-61 runs D(real) then D(fake).  NonSaturatingDiscLoss sends [real; fake] through once under bn_groups(2):
+    loss, every parameter gradient and every BatchNorm buffer (two running-stat updates, real first; num_batches_tracked += 2)
+    must match the two-pass form."""
+    DL = importlib.import_module("attention-gan_amd.losses.disc_loss").NonSaturatingDiscLoss
+    torch.manual_seed(4)
+    da, db = DISC.Disc128(8).to(DEV), DISC.Disc128(8).to(DEV)
+    db.load_state_dict(da.state_dict())
+    gen = torch.Generator().manual_seed(4)
+    real = (torch.rand(6, 3, 128, 128, generator=gen) * 2 - 1).to(DEV)
+    fake = (torch.rand(6, 3, 128, 128, generator=gen) * 2 - 1).to(DEV)
+    one, two = DL(), DL()
+    two.batch_pairs = False
+    la = one.get_loss(da, fake, real)
+    lb = two.get_loss(db, fake, real)
+    la.backward()
+    lb.backward()
+    assert_close(la, lb, 1e-6, "loss")
+    for (k, pa), (_, pb) in zip(da.named_parameters(), db.named_parameters()):
+        assert_close(pa.grad, pb.grad, 1e-4, f"grad {k}")
+    for (k, ba), (_, bb) in zip(da.named_buffers(), db.named_buffers()):
+        if k.endswith("num_batches_tracked"):
+            assert int(ba) == int(bb) == 2, k
+        else:
+            assert_close(ba, bb, 1e-6, f"buffer {k}")
+
+
 def test_measurement_hook_times_the_main_conv_kernel():
     """agan_timer_arm: the next conv call records the event pair around its main kernel (bench.py's roofline timing).  One-shot:
     a second call without re-arming leaves the events untouched."""
