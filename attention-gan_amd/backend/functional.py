@@ -427,8 +427,8 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Opti
 # Batch groups: a discriminator update runs the real and the fake batch through the same weights.  The reference does two
 # forward passes (disc_loss.py:55-61), so every BatchNorm sees each batch on its own: batch statistics per pass, two running-
 # statistic updates in call order.  `with bn_groups(2)` lets one pass over the concatenated [real; fake] batch reproduce that:
-# each BatchNorm call treats the batch axis as `groups` consecutive sub-batches and runs its kernels per sub-batch (statistics,
-# running-stat update and normalisation in group order; the backward accumulates gamma/beta gradients over the groups).  The
+# each BatchNorm call treats the batch axis as `groups` consecutive sub-batches (include/agan.h: agan_bn_train_fwd): statistics,
+# running-stat update and normalisation per sub-batch in order; the backward sums gamma/beta gradients over the groups.  The
 # convolutions in between simply see twice the pixels -- half the launches, better-filled tiles on the deep 4x4..16x16 layers.
 _BN_GROUPS = [1]
 
@@ -465,11 +465,8 @@ class _BnActFn(Function):
             invstd = torch.empty_like(mean)
             nbytes = lib.agan_bn_train_fwd_ws_bytes(Bg, C, HW)
             ws, wsp = _ws(nbytes, x)
-            for k in range(groups):                           # same stream: the running-stat updates happen in group order
-                sl = slice(k * Bg, (k + 1) * Bg)
-                L.call("agan_bn_train_fwd", _p(x[sl]), _p(g), _p(b), _p(res[sl]) if res is not None else None, _p(out[sl]),
-                       _p(mean[k]), _p(invstd[k]), _p(running_mean), _p(running_var), _p(nbt), Bg, C, HW, float(eps),
-                       float(momentum), act, wsp, nbytes, _stream())
+            L.call("agan_bn_train_fwd", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
+                   _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, groups, wsp, nbytes, _stream())
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
@@ -496,10 +493,8 @@ class _BnActFn(Function):
             raise L.AganError("BatchNorm weight/bias gradient destinations out of step")
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(Bg, C, HW)
         ws, wsp = _ws(nbytes, x)
-        for k in range(groups):                               # gamma/beta gradients: group 0 writes (or adds), the rest add
-            sl = slice(k * Bg, (k + 1) * Bg)
-            L.call("agan_bn_act_bwd", _p(x[sl]), _p(dout[sl]), _p(mean[k]), _p(invstd[k]), _p(g), _p(b), _p(dx[sl]), _p(dgbuf),
-                   _p(dbbuf), Bg, C, HW, ctx.act, gacc if k == 0 else 1, wsp, nbytes, _stream())
+        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
+               ctx.act, gacc, groups, wsp, nbytes, _stream())
         dres = dout if ctx.has_res else None
         return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 

@@ -48,10 +48,10 @@ _SIGNATURES = {
     "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "agan_bn_train_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_bn_train_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
+    "agan_bn_train_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_size_t, _P]),
     "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_act_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "agan_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "agan_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "agan_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -603,41 +603,56 @@ size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW) {
 
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
-                    void* ws, size_t ws_bytes, void* stream) {
+                    int groups, void* ws, size_t ws_bytes, void* stream) {
     AGAN_REQUIRE(x && dout && mean && invstd && gamma && beta && dx && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_bwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
-    if (ws_bytes < agan_bn_act_bwd_ws_bytes(B, C, HW)) {
+    AGAN_REQUIRE(groups >= 1 && B % groups == 0, "bn_act_bwd: batch %d does not split into %d groups", B, groups);
+    const int Bg = B / groups;
+    if (ws_bytes < agan_bn_act_bwd_ws_bytes(Bg, C, HW)) {
         set_error("bn_act_bwd: workspace too small");
         return AGAN_EWORKSPACE;
     }
     hipStream_t st = as_stream(stream);
-    if (HW > 1 && (long long)B * HW <= kSmallN) {
-        const int Cb = act == AGAN_ACT_GLU ? C / 2 : C;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Cb), dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, accumulate)
-        if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
-        else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
-        else AGAN_L(AGAN_ACT_NONE);
-#undef AGAN_L
-        return check_launch("bn_act_bwd/small");
-    }
-    const int nchunk = bwd_chunks(B, C, HW);
     const bool glu = act == AGAN_ACT_GLU;
     const int Co = glu ? C / 2 : C;
+    if (HW > 1 && (long long)Bg * HW <= kSmallN) {
+        for (int gi = 0; gi < groups; ++gi) {      // (one launch per group: see agan_bn_train_fwd)
+            const float* xg = x + (size_t)gi * Bg * C * HW;
+            const float* dg = dout + (size_t)gi * Bg * Co * HW;
+            float* dxg = dx + (size_t)gi * Bg * C * HW;
+            const int acc = gi == 0 ? accumulate : 1;
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc)
+            if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
+            else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
+            else AGAN_L(AGAN_ACT_NONE);
+#undef AGAN_L
+        }
+        return check_launch("bn_act_bwd/small");
+    }
+    const int nchunk = bwd_chunks(Bg, C, HW);
     double* part = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(part + (size_t)C * nchunk * 4);
     dim3 grid(Co, nchunk);
-    if (glu) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_GLU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
-    else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, B, C, HW, nchunk, part);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, B * HW, glu, dgamma, dbeta, coef, accumulate);
     const bool vec = (HW & 3) == 0;
-    const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
-#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, dout, mean, invstd, gamma, beta, coef, dx, B, C, HW)
-    if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
-    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
-    else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
+    const int blocks = ew_blocks((size_t)Bg * Co * HW / (vec ? 4 : 1));
+    for (int gi = 0; gi < groups; ++gi) {      // group 0 writes (or adds to) the gamma/beta gradients, the others add
+        const float* xg = x + (size_t)gi * Bg * C * HW;
+        const float* dg = dout + (size_t)gi * Bg * Co * HW;
+        const float* mg = mean + (size_t)gi * C;
+        const float* ig = invstd + (size_t)gi * C;
+        float* dxg = dx + (size_t)gi * Bg * C * HW;
+        const int acc = gi == 0 ? accumulate : 1;
+        if (glu) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_GLU>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
+        else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
+        else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, Bg * HW, glu, dgamma, dbeta, coef, acc);
+#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW)
+        if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
+        else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
+        else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
 #undef AGAN_L
+    }
     return check_launch("bn_act_bwd");
 }
 
@@ -687,24 +702,43 @@ size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW) {
 
 int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
                       float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
-                      float momentum, int act, void* ws, size_t ws_bytes, void* stream) {
+                      float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream) {
     AGAN_REQUIRE(x && gamma && beta && out && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_train_fwd: bad argument");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_train_fwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
     AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_train_fwd: residual only with ACT_NONE");
     AGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running_mean/var must come together");
-    if (HW > 1 && (long long)B * HW <= kSmallN) {
+    AGAN_REQUIRE(groups >= 1 && B % groups == 0, "bn_train_fwd: batch %d does not split into %d groups", B, groups);
+    const int Bg = B / groups;
+    const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
+    if (HW > 1 && (long long)Bg * HW <= kSmallN) {
+        // one launch per group: a workgroup walking both groups itself was measured 2 % slower on the whole step (these launches
+        // are latency-bound; two short ones overlap tail to head)
         hipStream_t st = as_stream(stream);
-        const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, x, gamma, beta, residual, out, mean, invstd, running_mean, running_var, nbt, B, C, HW, eps, momentum)
-        if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
-        else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
-        else AGAN_L(AGAN_ACT_NONE);
+        for (int gi = 0; gi < groups; ++gi) {
+            const float* xg = x + (size_t)gi * Bg * C * HW;
+            const float* rg = residual ? residual + (size_t)gi * Bg * Co * HW : nullptr;
+            float* og = out + (size_t)gi * Bg * Co * HW;
+            float* mg = mean + (size_t)gi * C;
+            float* ig = invstd + (size_t)gi * C;
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum)
+            if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
+            else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
+            else AGAN_L(AGAN_ACT_NONE);
 #undef AGAN_L
+        }
         return check_launch("bn_train_fwd/small");
     }
-    if (int e = agan_bn_stats(x, B, C, HW, eps, mean, invstd, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream)) return e;
-    return agan_bn_act_fwd(x, mean, invstd, gamma, beta, residual, out, B, C, HW, act, stream);
+    for (int gi = 0; gi < groups; ++gi) {      // same stream: statistics, running-stat update and apply in group order
+        const float* xg = x + (size_t)gi * Bg * C * HW;
+        float* mg = mean + (size_t)gi * C;
+        float* ig = invstd + (size_t)gi * C;
+        if (int e = agan_bn_stats(xg, Bg, C, HW, eps, mg, ig, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream)) return e;
+        if (int e = agan_bn_act_fwd(xg, mg, ig, gamma, beta, residual ? residual + (size_t)gi * Bg * Co * HW : nullptr,
+                                    out + (size_t)gi * Bg * Co * HW, Bg, C, HW, act, stream))
+            return e;
+    }
+    return AGAN_OK;
 }
 
 }  // extern "C"

@@ -134,16 +134,20 @@ int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, cons
                     const float* residual, float* out, int B, int C, int HW, int act, void* stream);
 /* Training-mode forward in one call: batch statistics (written to mean/invstd for the backward, folded into the running
  * statistics) + normalise + activation.  Tensors with B*HW <= 8192 per channel run as ONE launch (a workgroup per channel
- * keeps the channel in registers between the two phases); larger ones as agan_bn_stats + agan_bn_act_fwd. */
+ * keeps the channel in registers between the two phases); larger ones as agan_bn_stats + agan_bn_act_fwd.
+ * groups: the batch axis is `groups` consecutive sub-batches of B/groups samples, each normalised with ITS OWN statistics
+ * (mean / invstd are [groups][C]); the running statistics receive one update per group, in batch order.  That is what
+ * `groups` separate forward passes through the layer do -- the discriminator's [real; fake] pass (disc_loss.py:55-61) uses 2.
+ * Workspace sizes are per group: call the *_ws_bytes functions with B/groups. */
 size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW);
 int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
                       float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, int HW,
-                      float eps, float momentum, int act, void* ws, size_t ws_bytes, void* stream);
-/* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU). */
+                      float eps, float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream);
+/* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU); gamma/beta gradients are summed over the groups. */
 size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
-                    void* ws, size_t ws_bytes, void* stream);
+                    int groups, void* ws, size_t ws_bytes, void* stream);
 /* plain activations without BN (first D conv + LeakyReLU layers.py:139-140; tanh generator_submodules.py:137) */
 int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream);
 int agan_act_bwd(const float* out, const float* dout, float* dx, size_t n, int act, void* stream);
