@@ -45,3 +45,11 @@ def rel_err(got, want):
 def assert_close(got, want, tol=RTOL, what=""):
     e = rel_err(got, want)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests; a pid-derived number can collide)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]

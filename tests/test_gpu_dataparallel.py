@@ -7,6 +7,8 @@ import os
 import pytest
 import torch
 
+from helpers import free_port
+
 pytestmark = pytest.mark.gpu
 
 GEN = importlib.import_module("attention-gan_amd.networks.generator")
@@ -60,7 +62,7 @@ def test_two_rank_step_equals_mean_of_shard_gradients():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 1000
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

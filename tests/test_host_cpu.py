@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, load, sub
+from helpers import GOLDEN, free_port, load, sub
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 agan = importlib.import_module("attention-gan_amd")
@@ -170,7 +170,7 @@ def test_data_parallel_gradient_exchange_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
