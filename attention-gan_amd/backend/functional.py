@@ -579,6 +579,7 @@ class _AttentionFn(Function):
                B, C, E, T, H * W, _stream())
         ctx.save_for_backward(images, words, w, proj, attn)
         ctx.scale, ctx.wdst = float(scale), wdst
+        ctx.set_materialize_grads(False)     # the attention map usually feeds nothing: no zero-filled 16 MB gradient for it
         return ctxt, attn
 
     @staticmethod
