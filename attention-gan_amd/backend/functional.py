@@ -652,6 +652,34 @@ def ns_disc_loss(p_real, p_fake):
     return _DiscLossFn.apply(p_real, p_fake)
 
 
+class _DiscLossPairedFn(Function):
+    """the same loss on one [real; fake] score vector (the paired discriminator pass): no slice views, so autograd does not
+    zero-fill and scatter two half gradients"""
+
+    @staticmethod
+    def forward(ctx, p):
+        p = _dev(p, "D([x; G(z)])")
+        n = p.numel() // 2
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        dp = torch.empty_like(p)
+        L.call("agan_disc_loss", _p(p[:n]), _p(p[n:]), _p(loss), _p(dp[:n]), _p(dp[n:]), n, _stream())
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g
+
+
+def ns_disc_loss_paired(p: Tensor) -> Tensor:
+    """NonSaturatingDiscLoss on a score vector whose first half is D(x) and second half D(G(z))"""
+    if p.dim() != 1 or p.numel() % 2:
+        raise L.AganError("ns_disc_loss_paired: expected a [2B] score vector")
+    return _DiscLossPairedFn.apply(p)
+
+
 class _GenLossFn(Function):
     @staticmethod
     def forward(ctx, p_fake):

@@ -33,10 +33,9 @@ class NonSaturatingDiscLoss(DiscLoss):
     def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
         if (self.batch_pairs and getattr(discriminator, "supports_batch_groups", False) and discriminator.training
                 and fake_images.is_cuda and fake_images.shape == real_images.shape):
-            n = real_images.shape[0]
             with HF.bn_groups(2):
                 score = discriminator(torch.cat([real_images, fake_images], dim=0))
-            return HF.ns_disc_loss(score[:n], score[n:])
+            return HF.ns_disc_loss_paired(score)
         dx_score = discriminator(real_images)
         dg_score = discriminator(fake_images)
         return HF.ns_disc_loss(dx_score, dg_score)
