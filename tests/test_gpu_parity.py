@@ -96,6 +96,10 @@ CONV_CASES = [
     ("up", 2, 16, 8, 16, 3, False),
     ("up", 3, 12, 5, 10, 3, False),        # odd spatial size
     ("up", 2, 64, 4, 64, 3, False),
+    # the paired [real; fake] discriminator pass at the metric batch (B = 48): deep small-M layers with the measured split rules
+    ("same", 48, 1024, 4, 512, 3, False),  # M = 768, K = 9216: split-K gather, unsplit 288-tile weight gradient
+    ("down", 48, 256, 8, 512, 4, False),   # M = 768, 4-class dgrad, pixel-split weight gradient
+    ("down", 48, 64, 32, 128, 4, False),   # M = 12288: 64-row / 128-row tile choice, whole-round pixel split
 ]
 
 
