@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int
 // ================================================================================================
 // forward / dgrad gather kernel
 // ================================================================================================
+// Build-time tuning / ablation switches (defaults are the shipped configuration; measurements in DESIGN.md §4):
+//   AGAN_GATHER_BK     K tile depth;   AGAN_GATHER_WAVES   occupancy target of __launch_bounds__;
+//   AGAN_ABLATE=1|2|3  drop the global loads | + the LDS stores | + the barrier of the K loop (wrong results: timing only)
 #ifndef AGAN_GATHER_BK
 #define AGAN_GATHER_BK 16
 #endif
