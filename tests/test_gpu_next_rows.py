@@ -2,6 +2,8 @@
 oracle, checkpoint/resume reproducing the following step bit for bit, and the DAMSM pre-training step (stock encoders + HIP
 losses) against the oracle's losses and torch's own Adam."""
 import importlib
+import os
+import sys
 
 import pytest
 import torch
@@ -249,3 +251,42 @@ def test_train_step_is_bit_reproducible():
     for ma, mb in zip([a.G] + a.Ds, [b.G] + b.Ds):
         for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
             assert torch.equal(va, vb), k
+
+
+def test_metric_config_step_properties():
+    """BASELINE.json configs[2] at full size (gf 32, df 64, emb 256, T 10, batch 24, 64/128/256 px): too large for the CPU oracle in
+    a test, so size-independent properties instead -- two fresh runs of two steps are bit-identical (no atomics at any size),
+    every loss is finite, each discriminator saw 2 BatchNorm batches per D update + 1 per G update (num_batches_tracked = 6
+    after two steps), Adam moved no weight by more than ~2 x lr, and the fakes are tanh-bounded."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+
+    def run():
+        step = bench.build(torch.device(DEV), 24, HF)
+        before = {(i, k): v.clone() for i, m in enumerate([step.G] + step.Ds) for k, v in m.state_dict().items()
+                  if v.dtype == torch.float32 and k.endswith("weight")}
+        words, sent, lens, reals = bench.synthetic_batch(torch.device(DEV), 24, seed=5)
+        for _ in range(2):
+            out = step.step(words, sent, lens, None, reals)
+        torch.cuda.synchronize()
+        return step, out, before
+    a, oa, before = run()
+    b, ob, _ = run()
+    for k in ("d_loss0", "d_loss1", "d_loss2", "g_total", "w_loss", "s_loss", "kl"):
+        assert torch.isfinite(oa[k]).all() and torch.equal(oa[k], ob[k]), k
+    for ma, mb in zip([a.G] + a.Ds, [b.G] + b.Ds):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), k
+    for d in a.Ds:
+        nbt = [int(v) for k, v in d.state_dict().items() if k.endswith("num_batches_tracked")]
+        assert nbt and all(n == 6 for n in nbt), nbt
+    moved = 0.0
+    for i, m in enumerate([a.G] + a.Ds):
+        for k, v in m.state_dict().items():
+            if (i, k) in before:
+                moved = max(moved, float((v - before[(i, k)]).abs().max()))
+    # Adam (b1 0.5, b2 0.999): |step 1| <= lr; |step 2| <= 1.054 lr (Cauchy-Schwarz on the bias-corrected m / sqrt(v))
+    assert 0.0 < moved <= 2 * 2e-4 * 1.05
+    for f in oa["fake_imgs"]:
+        assert float(f.abs().max()) <= 1.0
