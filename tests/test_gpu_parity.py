@@ -313,6 +313,54 @@ def test_conv_with_fused_leaky_relu_vs_torch(kind, B, Cin, H, Cout, k):
     assert_close(bd.grad, br.grad, RTOL, "db")
 
 
+def test_conv_engine_random_shapes_vs_torch_cpu():
+    """Seeded sweep over shapes the fixed cases do not enumerate: non-square images, odd sizes, 1..1024 channels, batch 1..48,
+    1x1 / 3x3 / 4x4-s2 / upsample+3x3, optional bias -- forward, data gradient, weight gradient and bias gradient against
+    torch's CPU convolution.  (Run with thousands of cases while the kernels were being rewritten; a slice stays here.)"""
+    import random
+    F = torch.nn.functional
+    rng = random.Random(20240)
+    done = 0
+    while done < 40:
+        kind = rng.choice(["same", "same", "down", "up"])
+        B = rng.choice([1, 2, 3, 5, 8, 24, 48])
+        Cin = rng.choice([1, 3, 5, 16, 31, 64, 100, 128, 257, 512, 1024])
+        Cout = rng.choice([1, 3, 4, 5, 17, 32, 48, 64, 96, 100, 128, 200, 512])
+        H = rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 64])
+        W = H if rng.random() < 0.7 else rng.choice([2, 4, 6, 8, 12, 16, 20])
+        k = {"same": rng.choice([1, 3]), "down": 4, "up": 3}[kind]
+        if kind == "down":
+            H, W = H + H % 2, W + W % 2
+        if 2.0 * B * H * W * Cout * Cin * k * k * (4 if kind == "up" else 1) > 1.5e9:
+            continue
+        bias = rng.random() < 0.4
+        g = torch.Generator().manual_seed(done)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g) if bias else None
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if bias else None
+        if kind == "same":
+            yr = F.conv2d(xr, wr, br, padding=k // 2)
+        elif kind == "down":
+            yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+        else:
+            yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, br, padding=1)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True) if bias else None
+        yd = HF.conv2d(xd, wd, bd, kind)
+        yd.backward(gy.to(DEV))
+        tag = f"{kind} B{B} {Cin}x{H}x{W}->{Cout} k{k} bias={bias}"
+        assert_close(yd, yr, RTOL, f"y {tag}")
+        assert_close(xd.grad, xr.grad, RTOL, f"dx {tag}")
+        assert_close(wd.grad, wr.grad, RTOL, f"dw {tag}")
+        if bias:
+            assert_close(bd.grad, br.grad, RTOL, f"db {tag}")
+        done += 1
+
+
 def test_paired_discriminator_pass_equals_two_passes():
     """disc_loss.py:55-61 runs D(real) then D(fake).  NonSaturatingDiscLoss sends [real; fake] through once under bn_groups(2):
     loss, every parameter gradient and every BatchNorm buffer (two running-stat updates, real first; num_batches_tracked += 2)
