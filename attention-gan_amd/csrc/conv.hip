@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int
 // Build-time tuning / ablation switches (defaults are the shipped configuration; measurements in DESIGN.md §4):
 //   AGAN_GATHER_BK     K tile depth;   AGAN_GATHER_WAVES   occupancy target of __launch_bounds__;
 //   AGAN_ABLATE=1|2|3  drop the global loads | + the LDS stores | + the barrier of the K loop (wrong results: timing only)
+#ifndef AGAN_XCD_REMAP
+#define AGAN_XCD_REMAP 1
+#endif
 #ifndef AGAN_GATHER_BK
 #define AGAN_GATHER_BK 16
 #endif
@@ -80,7 +83,20 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
     const int wm = wave % WM, wn = wave / WM;
     const int cls = blockIdx.z / ksplit, split = blockIdx.z - cls * ksplit;
     const int py = cls / g.OS, px = cls - py * g.OS;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  Pixel tiles that are
+    // neighbours in the image share input rows (the 3x3 / 4x4 halo), so each XCD takes a CONTIGUOUS run of pixel tiles: id x
+    // runs on XCD x % 8 and gets the (x / 8)-th tile of that XCD's run -- a bijection on [0, mtiles).
+#if AGAN_XCD_REMAP
+    int mt;
+    {
+        const int mtiles = gridDim.x, q = mtiles >> 3, r = mtiles & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = xcd < r ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    }
+#else
+    const int mt = blockIdx.x;
+#endif
+    const int m0 = mt * BM, n0 = blockIdx.y * BN;
     const int kbeg = split * kchunk, kend = min(g.K, kbeg + kchunk);
     const int nkt = cdiv(kend - kbeg, BK);
     const int ihw = g.IH * g.IW;
