@@ -150,6 +150,20 @@ __host__ __device__ inline int pack_dims(int mode, int cout, int cin, int kh, in
     return -1;
 }
 
+// ---- XCD-aware workgroup order ---------------------------------------------------------------------------------------
+// The dispatcher hands consecutive workgroup ids (x fastest, then y, then z) round-robin to the 8 XCDs, each with its own L2.
+// Workgroups that share operand data (neighbouring pixel tiles: the conv halo; the (k, cout) tiles of one pixel chunk in the
+// weight gradient) should therefore NOT have consecutive ids.  xcd_contiguous maps the linear id L in [0, T) to a position F in
+// [0, T) such that every XCD walks a CONTIGUOUS range of F (a bijection): order the work so that data-sharing tiles are
+// adjacent in F and they land on one XCD, close in time.
+__device__ __forceinline__ int linear_block_id() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+__device__ __forceinline__ int xcd_contiguous(int L, int T) {
+    const int xcd = L & 7, idx = L >> 3;
+    int start = 0;
+    for (int i = 0; i < xcd; ++i) start += (T - i + 7) >> 3;       // ids with id % 8 == i
+    return start + idx;
+}
+
 // ---- launch plans ------------------------------------------------------------------------------------------------
 struct GatherPlan {
     int bn, mtiles, ntiles, ncls, ksplit, kchunk;
