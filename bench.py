@@ -115,6 +115,15 @@ class ConvTimer:
         return by
 
 
+def baseline_metric_name():
+    """the headline metric exactly as BASELINE.json words it (the file ships with the repo)"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, ValueError, KeyError):
+        return "train images/sec at 256x256 stage-3, batch 24/GPU"
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch from the committed PMC run (profiles/r01_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes,
     gfx950 x2 read correction); None if that kernel was not measured."""
@@ -307,7 +316,7 @@ def main():
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "timing": roofline_timing, "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),
                         "share_of_step_time": round((ms / ROOF_STEPS) / (elapsed / args.steps * 1e3), 3)}
         line = {
-            "metric": "train images/sec at 256x256 stage-3, batch 24/GPU",
+            "metric": baseline_metric_name(),
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
