@@ -187,8 +187,8 @@ def cpu_baseline(batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
                     help="MFMA mode of the conv engine: f32 = exact fp32 products (parity mode, default); bf16x3 = 3-term bf16 split")
