@@ -32,7 +32,13 @@ def get_precision() -> int:
     return _PRECISION[0]
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> c_void_p:
+    """raw handle of torch's current HIP stream (what every library call enqueues on)"""
+    if _RAW_STREAM is not None:              # ~10x cheaper than building a torch.cuda.Stream object per launch
+        return c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
