@@ -240,27 +240,39 @@ def main():
     def eager_step():
         return step.step(words, sent, lens_dev, None, reals)
 
-    # Launch mode.  Eager: ~1000 launches per step from Python (~14 ms of host time, hidden behind ~29 ms of GPU time on an
-    # unloaded host).  Graph: the whole step captured once and replayed (no host work, but hipGraphLaunch adds per-node cost:
-    # measured 813 vs 830 images/s on an idle box).  `auto` at N=1 captures the graph, times a few UNTIMED steps of each
-    # and keeps the faster one for the measured region; under torch.distributed the step stays eager (RCCL is not captured).
+    # Launch mode.  Eager: ~850 launches per step from Python (~12 ms of host time, hidden behind ~27 ms of GPU time on an
+    # unloaded host).  Graph: the whole step captured once and replayed -- no host work, but hipGraphLaunch adds per-node cost
+    # and a process that has captured runs ~1.5 % slower even eagerly (857 vs 877 images/s measured).  `auto` at N=1 therefore
+    # first checks, in UNTIMED steps, whether eager is launch-bound on this host (enqueue time vs step time); only then does it
+    # capture the graph and keep whichever replays/steps faster.  Under torch.distributed the step stays eager (RCCL is not
+    # captured).
+    def probe(fn, n=6):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t_host = (time.perf_counter() - t0) / n
+        torch.cuda.synchronize()
+        return t_host, (time.perf_counter() - t0) / n
+
     use_graph = args.graph == "on"
     graphed = None
-    if world == 1 and args.graph in ("on", "auto"):
-        graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
     if world == 1 and args.graph == "auto":
-        def probe(fn, n=4):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n
-        t_eager, t_graph = probe(eager_step), probe(graphed.replay)
-        use_graph = t_graph < t_eager
-        print(f"[bench] launch probe: eager {t_eager * 1e3:.2f} ms/step, graph replay {t_graph * 1e3:.2f} ms/step -> "
-              f"{'graph' if use_graph else 'eager'}", file=sys.stderr, flush=True)
+        for _ in range(2):
+            eager_step()
+        t_host, t_eager = probe(eager_step)
+        if t_host > 0.85 * t_eager:                      # the host cannot keep the GPU fed: try the graph
+            graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
+            t_graph = min(probe(graphed.replay)[1], probe(graphed.replay)[1])
+            use_graph = t_graph < t_eager
+            print(f"[bench] eager is launch-bound here (host {t_host * 1e3:.1f} of {t_eager * 1e3:.1f} ms/step); graph replay "
+                  f"{t_graph * 1e3:.2f} ms/step -> {'graph' if use_graph else 'eager'}", file=sys.stderr, flush=True)
+        else:
+            print(f"[bench] eager: host enqueue {t_host * 1e3:.1f} ms of a {t_eager * 1e3:.2f} ms step -> eager (no graph capture)",
+                  file=sys.stderr, flush=True)
+    elif world == 1 and args.graph == "on":
+        graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
     one_step = graphed.replay if use_graph else eager_step
 
     for _ in range(args.warmup):
