@@ -275,7 +275,7 @@ def set_launch_observer(obs) -> None:
 
 
 def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "",
-            act: int = 0) -> None:
+            act: int = 0, lrelu_mask: Optional[Tensor] = None) -> None:
     lib = L.load()
     nbytes = lib.agan_conv_gather_ws_bytes(byref(g), _PRECISION[0])
     ws, wsp = _ws(nbytes, x)
@@ -283,7 +283,8 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
     obs = _OBSERVER[0]
     if obs is not None:
         obs.begin(kind, phase, g)
-    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], act, wsp, nbytes, _stream())
+    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], act, _p(lrelu_mask), wsp, nbytes,
+           _stream())
     if obs is not None:
         obs.end()
 
@@ -343,9 +344,20 @@ def join_side_stream() -> None:
         _SIDE_DIRTY[key] = False
 
 
+class ActHandoff:
+    """Links a conv whose epilogue applied LeakyReLU (the producer) to the ONE conv that consumes its output: the consumer's
+    data-gradient epilogue multiplies by LeakyReLU'(its input) -- which is the producer's activation backward -- and says so
+    here, so the producer skips the separate activation-backward pass.  One object per forward call of the pair."""
+    __slots__ = ("masked",)
+
+    def __init__(self):
+        self.masked = False
+
+
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst, act: int = 0):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst, act: int = 0,
+                handoff_out: Optional[ActHandoff] = None, handoff_in: Optional[ActHandoff] = None):
         x = _dev(x, "conv input")
         w = _dev(weight.detach(), "conv weight")
         B, Cin, H, W = x.shape
@@ -361,6 +373,9 @@ class _ConvFn(Function):
         else:                       # fused LeakyReLU: the backward needs the sign of the output
             ctx.save_for_backward(x, w, out)
         ctx.kind, ctx.has_bias, ctx.cache, ctx.wdst, ctx.bdst, ctx.act = kind, bias is not None, cache, wdst, bdst, act
+        ctx.handoff_out = handoff_out if act != L.ACT_NONE else None
+        # the consumer can fold the producer's LeakyReLU backward into its dgrad epilogue on the fp32 MFMA path (> 4 channels)
+        ctx.handoff_in = handoff_in if (handoff_in is not None and _PRECISION[0] == L.PREC_F32 and Cin > 4) else None
         return out
 
     @staticmethod
@@ -369,10 +384,13 @@ class _ConvFn(Function):
         x, w = ctx.saved_tensors[:2]
         dy = _dev(dy, "conv grad")
         if ctx.act != L.ACT_NONE:
-            out = ctx.saved_tensors[2]
-            dz = torch.empty_like(dy)
-            L.call("agan_act_bwd", _p(out), _p(dy), _p(dz), out.numel(), ctx.act, _stream())
-            dy = dz
+            if ctx.handoff_out is not None and ctx.handoff_out.masked:
+                ctx.handoff_out.masked = False          # the consumer's dgrad epilogue already applied LeakyReLU'(out)
+            else:
+                out = ctx.saved_tensors[2]
+                dz = torch.empty_like(dy)
+                L.call("agan_act_bwd", _p(out), _p(dy), _p(dz), out.numel(), ctx.act, _stream())
+                dy = dz
         B, Cin, H, W = x.shape
         Cout, _, kh, kw = w.shape
         gf, pf, gd, pd, _ = conv_geoms(ctx.kind, B, Cin, H, W, Cout, kh)
@@ -403,8 +421,11 @@ class _ConvFn(Function):
                 L.call("agan_bias_grad", _p(dy), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad")
-        return dx, dw, db, None, None, None, None, None
+            mask = x if ctx.handoff_in is not None else None       # x is the producer's LeakyReLU output
+            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask)
+            if mask is not None:
+                ctx.handoff_in.masked = True
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv_fuses_activation(act: int, cout: int) -> bool:
@@ -413,11 +434,13 @@ def conv_fuses_activation(act: int, cout: int) -> bool:
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None,
-           wdst=None, bdst=None, act: int = 0) -> Tensor:
+           wdst=None, bdst=None, act: int = 0, handoff_out: Optional[ActHandoff] = None,
+           handoff_in: Optional[ActHandoff] = None) -> Tensor:
     """conv forward with autograd (dgrad + wgrad kernels).  kind: 'same' | 'down' | 'up' (conv_geoms).
     wdst / bdst: optional flat-gradient destinations of weight / bias (grad_dst(param)).
-    act: ACT_LRELU applies the activation in the conv epilogue (see conv_fuses_activation)."""
-    return _ConvFn.apply(x, weight, bias, kind, cache, wdst, bdst, act)
+    act: ACT_LRELU applies the activation in the conv epilogue (see conv_fuses_activation).
+    handoff_out / handoff_in: one ActHandoff shared by a fused conv+LeakyReLU and the single conv consuming its output."""
+    return _ConvFn.apply(x, weight, bias, kind, cache, wdst, bdst, act, handoff_out, handoff_in)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, cache: Optional[dict] = None, wdst=None, bdst=None) -> Tensor:

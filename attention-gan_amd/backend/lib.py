@@ -41,7 +41,7 @@ _SIGNATURES = {
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
-    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, c_size_t, _P]),
+    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -61,7 +61,8 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                const int2* __restrict__ ktab, const Geom g, const int ksplit,
-                                                               const int kchunk, const size_t slab, const int act) {
+                                                               const int kchunk, const size_t slab, const int act,
+                                                               const float* __restrict__ lrelu_mask) {
     constexpr int BK = AGAN_GATHER_BK;
     constexpr int NG = 256 / BM;       // wave-uniform k groups for the pixel-major A loads
     constexpr int AK = BK / NG;        // k rows per thread per tile
@@ -249,6 +250,10 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
     const bool add_bias = (bias != nullptr) && (ksplit == 1);
     const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);          // fused LeakyReLU(0.2) (a split launch applies it in the slab sum)
+    // data-gradient launches: out *= LeakyReLU'(mask) where mask is the tensor the output is the gradient OF (same shape) -- the
+    // backward of the activation that produced this conv's input, folded into the epilogue instead of a separate pass
+    const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mo = m0 + wm * WTM + tm * 32 + l31;
@@ -265,7 +270,9 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
                 float v = acc[tn][tm][r];
                 if (add_bias) v += bias[min(n, g.Cout - 1)];
                 if (lrelu) v = v > 0.f ? v : 0.2f * v;
-                buf_store(rout, (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB, v);
+                const unsigned off = (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB;
+                if (masked) v = buf_load(rmask, off) > 0.f ? v : 0.2f * v;
+                buf_store(rout, off, v);
             }
         }
     }
@@ -275,7 +282,8 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
 // 8th slab (4 independent loads in flight), the 8 partial sums meet in LDS.  Deterministic (fixed summation order).
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
                                                         const float* __restrict__ bias, int C, int HW,
-                                                        float* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE) {
+                                                        float* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE,
+                                                        const float* __restrict__ lrelu_mask = nullptr) {
     __shared__ float4 part[8][32];
     const size_t n4 = n / 4;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -319,6 +327,11 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
                 a.x = a.x > 0.f ? a.x : 0.2f * a.x; a.y = a.y > 0.f ? a.y : 0.2f * a.y;
                 a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w;
             }
+            if (lrelu_mask) {
+                const float4 m = *reinterpret_cast<const float4*>(lrelu_mask + i * 4);
+                a.x = m.x > 0.f ? a.x : 0.2f * a.x; a.y = m.y > 0.f ? a.y : 0.2f * a.y;
+                a.z = m.z > 0.f ? a.z : 0.2f * a.z; a.w = m.w > 0.f ? a.w : 0.2f * a.w;
+            }
             *reinterpret_cast<float4*>(out + i * 4) = a;
         }
         __syncthreads();
@@ -331,16 +344,17 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
         if (bias) a += bias[(q / HW) % C];
         if (accumulate) a += out[q];
         if (act == AGAN_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
+        if (lrelu_mask) a = lrelu_mask[q] > 0.f ? a : 0.2f * a;
         out[q] = a;
     }
 }
 
 template <int BN, int WM, int WN>
 void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
-                   const GatherPlan& p, int act, hipStream_t st) {
+                   const GatherPlan& p, int act, const float* lrelu_mask, hipStream_t st) {
     dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
     hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
-                       p.kchunk, p.slab, act);
+                       p.kchunk, p.slab, act, lrelu_mask);
 }
 
 // ================================================================================================
@@ -838,12 +852,14 @@ int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
 }
 
 int agan_conv_gather(const float* in, const void* wkv, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
-                     int prec, int act, void* ws, size_t ws_bytes, void* stream) {
+                     int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream) {
     const float* wk = static_cast<const float*>(wkv);
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || (act == AGAN_ACT_LRELU && prec == AGAN_PREC_F32 && gg->Cout > 4),
                  "conv_gather: fused activation %d not available for this call (fp32 MFMA path, LeakyReLU only)", act);
+    AGAN_REQUIRE(!lrelu_mask || (prec == AGAN_PREC_F32 && gg->Cout > 4 && act == AGAN_ACT_NONE),
+                 "conv_gather: the LeakyReLU-derivative mask needs the fp32 MFMA path and no other activation");
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_gather: precision mode %d not built in this version", prec);
     const Geom g = make_geom(gg);
@@ -862,16 +878,16 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
     timer_begin(st);
     if (prec == AGAN_PREC_BF16X3) launch_gather_bf16x3(in, wkv, bias, dst, ktab, g, p, st);
-    else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, st);
-    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, act, st);
-    else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, act, st);
+    else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
+    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
+    else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
     timer_end(st);
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
         const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
-                           bias, g.Cout, g.OH * g.OW, out, 0, act);
+                           bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask);
         return check_launch("conv_gather/sum_slabs");
     }
     return AGAN_OK;

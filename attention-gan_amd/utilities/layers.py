@@ -35,10 +35,11 @@ class HipConv2d(nn.Conv2d):
         self.kind = kind
         self._packed = {}        # packed-weight cache (layout copies for the kernels; not part of state_dict)
 
-    def forward(self, x: Tensor, act: int = L.ACT_NONE) -> Tensor:
-        """`act` (only where HF.conv_fuses_activation allows it) applies the following activation in the conv epilogue."""
+    def forward(self, x: Tensor, act: int = L.ACT_NONE, handoff_out=None, handoff_in=None) -> Tensor:
+        """`act` (only where HF.conv_fuses_activation allows it) applies the following activation in the conv epilogue;
+        the handoffs link such a conv to its single consumer (HF.ActHandoff)."""
         return HF.conv2d(x, self.weight, self.bias, self.kind, self._packed, HF.grad_dst(self.weight),
-                         HF.grad_dst(self.bias) if self.bias is not None else None, act)
+                         HF.grad_dst(self.bias) if self.bias is not None else None, act, handoff_out, handoff_in)
 
 
 class HipLinear(nn.Linear):
@@ -106,12 +107,17 @@ class FusedChain(nn.Module):
 
     def run(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         last = len(self._stages) - 1
+        handoff = None
         for i, st in enumerate(self._stages):
             conv = getattr(self, st.conv)
             if st.bn is None and HF.conv_fuses_activation(st.act, conv.out_channels):
-                x = conv(x, st.act)                       # conv + LeakyReLU in one kernel (no BatchNorm in between)
+                # conv + LeakyReLU in one kernel (no BatchNorm in between); if a conv of this chain is its only consumer, that
+                # conv's dgrad epilogue does the activation backward as well
+                handoff = HF.ActHandoff() if i < last else None
+                x = conv(x, st.act, handoff, None)
                 continue
-            y = conv(x)
+            y = conv(x, L.ACT_NONE, None, handoff)
+            handoff = None
             if st.bn is not None:
                 x = getattr(self, st.bn).fused(y, st.act, residual if i == last else None)
             elif st.act != L.ACT_NONE:

@@ -104,8 +104,11 @@ size_t agan_conv_ktable_elems(const agan_conv_geom* g);
 int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
 
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
+/* lrelu_mask (optional, data-gradient launches): a tensor of the OUTPUT's shape; out is multiplied by LeakyReLU'(mask) = 1 where
+ * mask > 0, else 0.2 -- the backward of the LeakyReLU that produced this conv's forward input (the mask is that input), folded
+ * into the epilogue so that the activation's backward needs no pass of its own. */
 int agan_conv_gather(const float* in, const void* wk, const float* bias, float* out, const agan_conv_geom* g,
-                     const int32_t* ktable, int prec, int act, void* ws, size_t ws_bytes, void* stream);
+                     const int32_t* ktable, int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream);
 
 /* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.
  * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).

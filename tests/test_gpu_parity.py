@@ -418,6 +418,57 @@ def test_measurement_hook_times_the_main_conv_kernel():
     L.call("agan_timer_destroy", e1)
 
 
+def test_leaky_relu_backward_in_the_consumer_dgrad_epilogue():
+    """encode_image_by_16times: the first conv applies LeakyReLU in its epilogue and the second conv's data-gradient epilogue
+    multiplies by LeakyReLU'(its input), so the activation has no backward pass of its own (HF.ActHandoff).  Same chain with
+    the hand-off disabled (separate activation-backward kernel): outputs and every gradient agree."""
+    torch.manual_seed(12)
+    a, b = LAY.Layers.encode_image_by_16times(16).to(DEV), LAY.Layers.encode_image_by_16times(16).to(DEV)
+    b.load_state_dict(a.state_dict())
+    x = (torch.rand(6, 3, 64, 64, device=DEV) * 2 - 1)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    made = []
+    real = HF.ActHandoff
+
+    def spy():
+        made.append(real())
+        return made[-1]
+    HF.ActHandoff = spy
+    try:
+        ya = a(xa)
+    finally:
+        HF.ActHandoff = real
+    assert len(made) == 1 and not made[0].masked
+    HF.ActHandoff = lambda: None
+    try:
+        yb = b(xb)
+    finally:
+        HF.ActHandoff = real
+    gy = torch.randn_like(ya)
+    calls = {"a": 0, "b": 0}
+    real_call = L.call
+
+    def counting(which):
+        def call(name, *args):
+            if name == "agan_act_bwd":
+                calls[which] += 1
+            return real_call(name, *args)
+        return call
+    L.call = counting("a")
+    try:
+        ya.backward(gy)
+        L.call = counting("b")
+        yb.backward(gy)
+    finally:
+        L.call = real_call
+    assert calls == {"a": 0, "b": 1}          # with the hand-off the activation backward launched nothing
+    assert made[0].masked is False            # set by the consumer, consumed (reset) by the producer
+    assert_close(ya, yb, 0.0 + 1e-7, "y")
+    assert_close(xa.grad, xb.grad, 1e-6, "dx")
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert_close(pa.grad, pb.grad, 1e-6, f"grad {k}")
+
+
 def test_batched_pack_equals_single_packs():
     """agan_pack_weights (one launch for a whole module) must write exactly what agan_pack_weight writes per tensor, for every
     layout mode, ragged channel counts and the zeroed padding columns (the batched buffers start as NaN)."""

@@ -45,7 +45,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.agan_packed_weight_bytes(L.PACK_UP_FWD, 64, 64, 3, 3, L.PREC_F32) == 4 * 64 * 4 * 64 * 4
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16X3) == 2 * 32 * 288 * 2  # hi+lo planes [Nld][Kp]
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16) == 0               # single-pass bf16 is not built
-    rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, 0, None, 0, None)
+    rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, 0, None, None, 0, None)
     assert rc == -1 and b"conv" in lib.agan_last_error()
 
 
