@@ -760,17 +760,40 @@ def _ids(class_ids, device) -> Optional[Tensor]:
     return torch.as_tensor(class_ids).to(device=device, dtype=torch.int64).contiguous()
 
 
+class _FuncAttentionFn(Function):
+    @staticmethod
+    def forward(ctx, query, context, gamma1, scale):
+        q, c = _dev(query, "query"), _dev(context, "context")
+        B, D, Lq = q.shape
+        ih, iw = c.shape[2], c.shape[3]
+        wctx = torch.empty((B, D, Lq), dtype=torch.float32, device=q.device)
+        attn = torch.empty((B, Lq, ih, iw), dtype=torch.float32, device=q.device)
+        L.call("agan_func_attention_fwd", _p(q), _p(c), gamma1, scale, _p(wctx), _p(attn), B, D, Lq, ih * iw, _stream())
+        ctx.save_for_backward(q, c)
+        ctx.hp = (gamma1, scale)
+        ctx.set_materialize_grads(False)
+        return wctx, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dwctx, dattn):
+        q, c = ctx.saved_tensors
+        B, D, Lq = q.shape
+        S = c.shape[2] * c.shape[3]
+        dq, dc = torch.empty_like(q), torch.empty_like(c)
+        if dwctx is None and dattn is None:
+            return dq.zero_(), dc.zero_(), None, None
+        dwctx = _dev(dwctx, "func_attention d(weightedContext)") if dwctx is not None else None
+        dattn = _dev(dattn, "func_attention d(attn)") if dattn is not None else None
+        L.call("agan_func_attention_bwd", _p(q), _p(c), _p(dwctx), _p(dattn), *ctx.hp, _p(dq), _p(dc), B, D, Lq, S, _stream())
+        return dq, dc, None, None
+
+
 def func_attention(query: Tensor, context: Tensor, gamma1: float = 4.0, scaled: bool = True):
-    """Forward of the parameter-free DAMSM attention (attention.py:82-120).  Inside the training step it only ever runs
-    fused into the words-loss kernels, which carry its backward; the standalone entry point is forward-only."""
-    q, c = _dev(query.detach(), "query"), _dev(context.detach(), "context")
-    B, D, Lq = q.shape
-    ih, iw = c.shape[2], c.shape[3]
-    wctx = torch.empty((B, D, Lq), dtype=torch.float32, device=q.device)
-    attn = torch.empty((B, Lq, ih, iw), dtype=torch.float32, device=q.device)
-    L.call("agan_func_attention_fwd", _p(q), _p(c), float(gamma1), (1.0 / math.sqrt(D)) if scaled else 1.0, _p(wctx), _p(attn),
-           B, D, Lq, ih * iw, _stream())
-    return wctx, attn
+    """The parameter-free DAMSM attention (attention.py:82-120), differentiable like the reference's plain-autograd version.
+    Inside the training step it runs fused into the words-loss kernels; this is the standalone entry point."""
+    D = query.shape[1]
+    return _FuncAttentionFn.apply(query, context, float(gamma1), (1.0 / math.sqrt(D)) if scaled else 1.0)
 
 
 class _WordsLossFn(Function):

@@ -407,8 +407,103 @@ __global__ __launch_bounds__(kNT) void func_attn_fwd_kernel(const float* __restr
         for (int w = 0; w < L; ++w) attn[((size_t)b * L + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
 }
 
+
+// standalone func_attention backward: (d wctx [B,D,L], d attn [B,L,S], either may be null) -> dquery [B,D,L], dcontext [B,D,S].
+// Same chain as the pair backward without the cosine head: recompute the forward of batch element b, then
+//   da2[r][w] = sum_d f[d][r] dc[d][w] + dattn[w][r];  region-softmax and word-softmax backward -> ds;
+//   dcontext[d][r] = sum_w dc[d][w] a2[r][w] + ds[r][w] q[d][w];   dquery[d][w] = sum_r ds[r][w] f[d][r].
+template <int TMAX>
+__global__ __launch_bounds__(kNT) void func_attn_bwd_kernel(const float* __restrict__ query, const float* __restrict__ context,
+                                                            const float* __restrict__ dwctx, const float* __restrict__ dattn, float gamma1,
+                                                            float scale, float* __restrict__ dquery, float* __restrict__ dcontext, int D, int L,
+                                                            int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
+    __shared__ float dotw[kNT / 64][TMAX];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* fb = context + (size_t)b * D * S;
+    float a1[TMAX];
+    pair_forward<TMAX, kNT>(sm, fb, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
+    if (tid < D) {
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) sm.c[tid][w] = (dwctx && w < L) ? dwctx[((size_t)b * D + tid) * L + w] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid;
+    const bool rlive = r < S;
+    float a2r[TMAX], da2[TMAX];
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) {
+        a2r[w] = rlive ? sm.a2[r][w] : 0.f;
+        da2[w] = (rlive && dattn && w < L) ? dattn[((size_t)b * L + w) * S + r] : 0.f;
+    }
+    if (rlive) {
+        for (int d = 0; d < D; ++d) {
+            const float fv = fb[(size_t)d * S + r];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) da2[w] += fv * sm.c[d][w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < TMAX; ++w) {
+        const float v = wave_sum(a2r[w] * da2[w]);
+        if (lane == 0) dotw[tid >> 6][w] = v;
+    }
+    __syncthreads();
+    float ds[TMAX];
+    {
+        float inner = 0.f;
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) {
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < kNT / 64; ++q) dot += dotw[q][w];
+            ds[w] = gamma1 * a2r[w] * (da2[w] - (w < L ? dot : 0.f));
+            inner += a1[w] * ds[w];
+        }
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) ds[w] = (w < L && rlive) ? a1[w] * (ds[w] - inner) * scale : 0.f;
+    }
+    if (rlive) {
+        float* dfb = dcontext + (size_t)b * D * S + r;
+        for (int d = 0; d < D; ++d) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) v += sm.c[d][w] * a2r[w] + ds[w] * sm.e[d][w];
+            dfb[(size_t)d * S] = v;
+        }
+    }
+    __syncthreads();
+    if (rlive) {
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) sm.a2[r][w] = ds[w];
+    }
+    __syncthreads();
+    if (tid < D) {
+        float de[TMAX];
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w) de[w] = 0.f;
+        const float* fr = fb + (size_t)tid * S;
+        for (int q = 0; q < S; ++q) {
+            const float fv = fr[q];
+#pragma unroll
+            for (int w = 0; w < TMAX; ++w) de[w] += fv * sm.a2[q][w];
+        }
+#pragma unroll
+        for (int w = 0; w < TMAX; ++w)
+            if (w < L) dquery[((size_t)b * D + tid) * L + w] = de[w];
+    }
+}
+
 template <int TMAX, int DR = kNT>
 constexpr size_t pair_smem_bytes() { return sizeof(PairSmem<TMAX, DR>); }
+
+// the [B][B] + 2[B] matrix of the contrastive kernel exceeds the default 64 KB dynamic-LDS limit at B >= 127 (kMaxB = 128)
+inline void allow_ce_smem() {      // (once per process: one process drives one GPU)
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(contrastive_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)((kMaxB * kMaxB + 2 * kMaxB) * sizeof(float)));
+    (void)attr_;
+}
 
 }  // namespace
 
@@ -438,6 +533,7 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     else if (T <= 16) AGAN_PAIR_FWD(16, kNT);
     else AGAN_PAIR_FWD(32, kNT);
 #undef AGAN_PAIR_FWD
+    allow_ce_smem();
     hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, lambda, loss, save, B);
     return check_launch("words_loss_fwd");
 }
@@ -488,6 +584,7 @@ int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64
     float* norms = dots + B * B;      // [2B]
     // sim is staged in dS's storage, then overwritten by the CE kernel's gradient
     hipLaunchKernelGGL(sent_scores_kernel, dim3(B), dim3(256), 0, st, cnn_code, rnn_code, gamma3, eps, dS, dots, norms, B, D);
+    allow_ce_smem();
     hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, dS, class_ids, lambda, loss, dS, B);
     return check_launch("sent_loss_fwd");
 }
@@ -516,6 +613,21 @@ int agan_func_attention_fwd(const float* query, const float* context, float gamm
         hipLaunchKernelGGL((func_attn_fwd_kernel<32>), dim3(B), dim3(kNT), pair_smem_bytes<32>(), st, query, context, gamma1, scale, wctx, attn, D, L, S);
     }
     return check_launch("func_attention_fwd");
+}
+
+int agan_func_attention_bwd(const float* query, const float* context, const float* dwctx, const float* dattn, float gamma1, float scale,
+                            float* dquery, float* dcontext, int B, int D, int L, int S, void* stream) {
+    AGAN_REQUIRE(query && context && dquery && dcontext, "func_attention_bwd: null pointer");
+    AGAN_REQUIRE(B >= 1 && D >= 1 && D <= kNT && S >= 1 && S <= kNT && L >= 1 && L <= 32, "func_attention_bwd: shape out of range");
+    hipStream_t st = as_stream(stream);
+    if (L <= 16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<16>());
+        hipLaunchKernelGGL((func_attn_bwd_kernel<16>), dim3(B), dim3(kNT), pair_smem_bytes<16>(), st, query, context, dwctx, dattn, gamma1, scale, dquery, dcontext, D, L, S);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(func_attn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<32>());
+        hipLaunchKernelGGL((func_attn_bwd_kernel<32>), dim3(B), dim3(kNT), pair_smem_bytes<32>(), st, query, context, dwctx, dattn, gamma1, scale, dquery, dcontext, D, L, S);
+    }
+    return check_launch("func_attention_bwd");
 }
 
 }  // extern "C"

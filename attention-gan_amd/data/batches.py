@@ -51,7 +51,8 @@ class ShardBatches:
 
     def __iter__(self) -> Iterator[Batch]:
         for path in self.paths:
-            z = np.load(path, allow_pickle=False, mmap_mode=None)
+            with np.load(path, allow_pickle=False, mmap_mode=None) as npz:
+                z = {k: npz[k] for k in ("words", "lengths", "class_ids", "img64", "img128", "img256")}   # NpzFile re-reads per access
             n = len(z["lengths"])
             order = self.rng.permutation(n) if self.shuffle else np.arange(n)
             for s in range(0, n - self.batch_size + 1, self.batch_size):

@@ -23,6 +23,29 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank_of(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+@torch.no_grad()
+def sync_buffers_(module: torch.nn.Module, group=None) -> None:
+    """Average the floating-point buffers (BatchNorm running statistics) over the replicas, in place; integer buffers
+    (num_batches_tracked) are identical on every rank by construction.  Called before a checkpoint is written."""
+    w = world_size(group)
+    if w == 1:
+        return
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(w)
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()
+
+
 def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Identical initial weights and BN buffers on every replica."""
     if world_size(group) == 1:

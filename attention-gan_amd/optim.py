@@ -54,9 +54,11 @@ class FlatAdam:
 
     # -- torch.optim-like surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
-        """Zero the flat gradient buffer and drop the per-parameter .grad references: the backward kernels write each
-        gradient straight into its slice of the flat buffer and autograd adopts that view (no accumulate kernels)."""
-        self.grad.zero_()
+        """Start a new backward: drop the per-parameter .grad references and re-arm the first-writer flags.  The flat gradient
+        buffer itself is NOT filled with zeros here (376 MB per step at the metric config): the first backward kernel that
+        produces a parameter's gradient overwrites its slice, and step() zeroes the slice of any parameter that received no
+        gradient at all in this backward (torch.optim.Adam skips such a parameter; a zero gradient keeps the fused update
+        branch-free and only decays its moments)."""
         for p in self.params:
             p.grad = None
             p._agan_grad_dst.written = False
@@ -74,11 +76,17 @@ class FlatAdam:
                 continue
             view = self.grad[o:o + p.numel()].view(p.shape)
             if g is not None:
-                if p._agan_grad_dst.written and HF.wgrad_side_stream_enabled():
-                    # the kernel wrote the slice on a side stream; a clone made by autograd on the main stream read it too early
-                    raise RuntimeError("FlatAdam: autograd cloned a gradient that was written on the weight-gradient side stream")
-                view.copy_(g)
-                copies += 1
+                if p._agan_grad_dst.written:
+                    # A backward kernel wrote (and possibly accumulated further uses into) the slice directly: the slice is the
+                    # truth.  A foreign p.grad here is a clone autograd made of the FIRST contribution (it clones instead of
+                    # adopting the view when something else still references it) -- copying it back would drop every later
+                    # in-kernel accumulation, so it is discarded.
+                    pass
+                else:
+                    view.copy_(g)
+                    copies += 1
+            elif not p._agan_grad_dst.written:
+                view.zero_()                  # no gradient reached this parameter in this backward
             p.grad = view
         return copies
 
@@ -93,7 +101,14 @@ class FlatAdam:
             raise RuntimeError("FlatAdam.step: parameters are not on an MI355X (no CPU fallback)")
 
     # -- checkpoint interchange with torch.optim.Adam.state_dict() (reference _save_weights, trainer.py:109-115) --
+    def sync_step_count(self) -> int:
+        """The device counter is the truth (a replayed HIP graph advances only it): mirror it on the host.  One host sync."""
+        if self.step_state.is_cuda:
+            self.step_count = int(self.step_state[0].item())
+        return self.step_count
+
     def state_dict(self) -> Dict:
+        self.sync_step_count()
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()

@@ -13,7 +13,7 @@ from torch import Tensor
 from torch.nn import Module
 
 from ..backend import functional as HF
-from ..dataparallel import GradBuckets, broadcast_module_, world_size
+from ..dataparallel import GradBuckets, broadcast_module_, rank_of, sync_buffers_, world_size
 from ..losses.disc_loss import NonSaturatingDiscLoss
 from ..losses.gen_loss import NonSaturatingGenLoss
 from ..losses.KL_loss import KL_loss
@@ -51,7 +51,7 @@ class ModelTrainer:
                 raise ValueError("_make_mask: maxlen is required for device-resident lengths")
             return (torch.arange(maxlen, device=lengths.device).view(1, -1) < lengths.view(-1, 1)).to(torch.int64)
         lens = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
-        mx = max(lens)
+        mx = max(lens) if maxlen is None else int(maxlen)
         return torch.tensor([[1] * l + [0] * (mx - l) for l in lens], dtype=torch.int64, device=_device())
 
     def _denormalise_single(self, tensor: Tensor) -> Tensor:
@@ -104,12 +104,18 @@ class ModelTrainer:
             print(f'Module {name} weights saved to {path}')
 
     def _load_weights(self, modules: List[Module], root_folder='saved_weights') -> None:
+        """Mirror of _save_weights: the k-th module of a class reads {ClassName}_{k}.pkl (k = 0: no suffix); nn.Modules are put
+        in eval mode like the reference does (trainer.py:124), optimisers are not."""
+        seen: Dict[str, int] = {}
         for m in modules:
             name = m.__class__.__name__
-            path = f"{root_folder}/{name}.pkl"
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            path = f"{root_folder}/{name}.pkl" if k == 0 else f"{root_folder}/{name}_{k}.pkl"
             try:
                 m.load_state_dict(torch.load(path, weights_only=True))
-                m.eval()
+                if isinstance(m, Module):
+                    m.eval()
                 print(f'Module {name} weights loaded from {path}')
             except FileNotFoundError:
                 print(f'FAILED: Module {name}... weights at path {path} were not found')
@@ -125,12 +131,18 @@ class GanTrainStep(ModelTrainer):
 
     def __init__(self, generator: Module, discriminators: Sequence[Module], image_encoder: Optional[Callable] = None,
                  gen_lr: float = 2e-4, disc_lr: float = 2e-4, gamma1: float = 4.0, gamma2: float = 5.0, gamma3: float = 10.0,
-                 wlambda: float = 5.0, slambda: float = 5.0, bucket_bytes: int = 64 << 20, group=None):
+                 wlambda: float = 5.0, slambda: float = 5.0, bucket_bytes: int = 64 << 20, group=None, seed: int = 0):
         super().__init__()
         self.G, self.Ds, self.image_encoder = generator, list(discriminators), image_encoder
         self.group = group
         for m in [self.G] + self.Ds:
             broadcast_module_(m, 0, group)
+        # noise and the CA-net's eps come from a generator of this object, seeded per RANK: replicas share the initial weights
+        # (broadcast above) but must draw different z / eps for their different captions
+        dev0 = next(self.G.parameters()).device
+        self.rank = rank_of(group)
+        self.rng = torch.Generator(device=dev0)
+        self.rng.manual_seed(int(seed) * 1000003 + self.rank)
         self.g_opt = FlatAdam(self.G.parameters(), lr=gen_lr, betas=(0.5, 0.999))
         self.d_opts = [FlatAdam(d.parameters(), lr=disc_lr, betas=(0.5, 0.999)) for d in self.Ds]
         self.g_buckets = GradBuckets(self.g_opt, bucket_bytes, group)
@@ -172,7 +184,9 @@ class GanTrainStep(ModelTrainer):
         labels = self._make_match_labels(b)
         mask = self._make_mask(lengths, word_embs.shape[2])
         if noise is None:
-            noise = self._make_noise(b, self.G.z_dim)
+            noise = torch.randn(b, self.G.z_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
+        if eps is None:
+            eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
         fakes, _attn, mu, logvar = self.G(noise, sent_embs, word_embs, mask, eps)
         out: Dict[str, Tensor] = {}
         # ---- discriminator updates (train.py:123-130) ----
@@ -243,6 +257,8 @@ class GanTrainStep(ModelTrainer):
         if "w_loss" in out:
             self.damsm_losses.append(out["w_loss"] + out["s_loss"])
         out["fake_imgs"] = [f.detach() for f in fakes]
+        out["attn_maps"] = [a.detach() for a in _attn]
+        out["mu"], out["logvar"] = mu.detach(), logvar.detach()
         return out
 
     # -- whole-step HIP graph ----------------------------------------------------------------------------------------
@@ -268,12 +284,19 @@ class GanTrainStep(ModelTrainer):
         torch.cuda.synchronize()
         HF.build_pack_tables()                             # the batched re-pack's job tables: host work, not capturable
         graph = torch.cuda.CUDAGraph()
+        if self.rng.device.type == "cuda":
+            graph.register_generator_state(self.rng)       # noise / eps draws inside the graph advance this generator on replay
         with torch.cuda.graph(graph):
             out = self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
         return GraphedStep(graph, out)
 
     # -- checkpoint / resume (the reference only saves, and its four `Adam` objects share one Adam.pkl) --
     def state_dict(self) -> Dict:
+        """Under torch.distributed the BatchNorm running statistics are per replica (local batches, as in the reference's
+        single-process BN); the checkpoint holds their MEAN over the ranks (sync_buffers_), so every rank writes the same file."""
+        if world_size(self.group) > 1:
+            for m in [self.G] + self.Ds:
+                sync_buffers_(m, self.group)
         return {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
                 "g_optim": self.g_opt.state_dict(), "d_optims": [o.state_dict() for o in self.d_opts]}
 
@@ -293,8 +316,9 @@ class GanTrainStep(ModelTrainer):
         try:
             b = word_embs.shape[0]
             if noise is None:
-                noise = self._make_noise(b, self.G.z_dim)
-            fakes, _, _, _ = self.G(noise, sent_embs, word_embs, self._make_mask(lengths))
+                noise = torch.randn(b, self.G.z_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
+            eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
+            fakes, _, _, _ = self.G(noise, sent_embs, word_embs, self._make_mask(lengths, word_embs.shape[2]), eps)
             return self._denormalise_multiple(fakes)
         finally:
             self.G.train(was_training)

@@ -185,6 +185,10 @@ int agan_attn_bwd(const float* images, const float* words, const float* w, const
 /* standalone func_attention forward (attention.py:82-120): query [B,D,L], context [B,D,S] -> wctx [B,D,L], attn [B,L,S] */
 int agan_func_attention_fwd(const float* query, const float* context, float gamma1, float scale, float* wctx, float* attn,
                             int B, int D, int L, int S, void* stream);
+/* its backward (plain autograd in the reference): dwctx [B,D,L] / dattn [B,L,S] are the upstream gradients (either may be NULL);
+ * writes dquery [B,D,L] and dcontext [B,D,S].  Recomputes the forward of each batch element; no atomics. */
+int agan_func_attention_bwd(const float* query, const float* context, const float* dwctx, const float* dattn, float gamma1,
+                            float scale, float* dquery, float* dcontext, int B, int D, int L, int S, void* stream);
 size_t agan_words_loss_save_elems(int B, int D, int T, int S);
 int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids,
                         float gamma1, float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps,

@@ -39,6 +39,7 @@ from losses.sentence_loss import SentenceLoss                              # noq
 from losses.disc_loss import NonSaturatingDiscLoss                         # noqa: E402
 from losses.gen_loss import NonSaturatingGenLoss                           # noqa: E402
 from losses.KL_loss import KL_loss                                         # noqa: E402
+from networks.rnn_encoder import RNNEncoder                                # noqa: E402
 
 CPU = torch.device("cpu")
 _captured_eps = []
@@ -306,7 +307,30 @@ def gen_train_step(seed=61, steps=2):
     save("a11_train_step", seed=seed, lens=npy(lens), class_ids=class_ids, **out)
 
 
+# --------------------------------------------------------------------------- f2 (text encoder, rnn_encoder.py:68-96)
+def gen_rnn_encoder(seed=51):
+    """Reference RNNEncoder (dropout 0 so that the draw-free forward is reproducible), captions padded to T = 10 with the
+    length pattern of the other fixtures; outputs, and gradients of the probe loss w.r.t. every parameter."""
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    vocab, embdim, nhidden, B, T = 50, 24, 32, 4, 10
+    m = RNNEncoder(vocabsize=vocab, embdim=embdim, dropprob=0.0, nhidden=nhidden)
+    m.train()
+    lens = torch.tensor([10, 7, 2, 10])
+    caps = torch.randint(1, vocab, (B, T), generator=g)
+    for i, l in enumerate(lens.tolist()):
+        caps[i, l:] = 0
+    before = sd(m)
+    w, s_ = m(caps, lens)
+    ((w * probe(w.shape, 0.7)).sum() + (s_ * probe(s_.shape, 0.8)).sum()).backward()
+    save("f2_rnn_encoder", seed=seed, dims=np.array([vocab, embdim, nhidden, B, T]), captions=npy(caps), lengths=npy(lens),
+         word_embs=npy(w), sent_embs=npy(s_), **before, **param_grads(m))
+
+
 def main():
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only == "f2_rnn_encoder":
+        return gen_rnn_encoder()
     gen_attention("a1_attention_small", B=4, C=8, E=32, T=10, hw=16, lens=[10, 7, 2, 10], seed=1)
     gen_attention("a1_attention_gen2", B=2, C=32, E=64, T=10, hw=64, lens=[10, 4], seed=2)
     gen_func_attention()
@@ -323,6 +347,7 @@ def main():
     gen_damsm()
     gen_small_losses()
     gen_train_step()
+    gen_rnn_encoder()
 
 
 if __name__ == "__main__":

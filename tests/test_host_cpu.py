@@ -124,10 +124,16 @@ def test_flat_adam_rehomes_parameters_and_speaks_adam_state_dict():
         assert p.data_ptr() == base + 4 * o and o % 4 == 0 and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * o
     lin(torch.randn(2, 5)).sum().backward()
     assert float(opt.grad.abs().sum()) > 0                      # autograd accumulated straight into the flat buffer
-    opt.zero_grad()
-    assert all(p.grad is None for p in opt.params) and float(opt.grad.abs().sum()) == 0
+    opt.zero_grad()                                             # no 4-byte-per-parameter fill: the first writer overwrites
+    assert all(p.grad is None and not p._agan_grad_dst.written for p in opt.params)
     lin(torch.randn(2, 5)).sum().backward()
     assert opt._rebind() == len(opt.params) and float(opt.grad.abs().sum()) > 0   # stock torch grads are copied in
+    opt.zero_grad()
+    lin[0](torch.randn(2, 5)).sum().backward()                  # the second layer receives no gradient in this backward ...
+    assert opt._rebind() == 2
+    o2 = opt.offsets[2]
+    assert float(opt.grad[o2:].abs().sum()) == 0 and float(opt.grad[:o2].abs().sum()) > 0    # ... so its slices are zeroed
+    assert all(p.grad.data_ptr() == opt.grad.data_ptr() + 4 * o for p, o in zip(opt.params, opt.offsets))
     sd = opt.state_dict()
     ref = torch.optim.Adam(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)).parameters(), lr=2e-4, betas=(0.5, 0.999))
     assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "params"} and sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
@@ -220,6 +226,31 @@ def test_encoder_plugins_on_cpu():
     assert sum(p.numel() for n, p in e.named_parameters() if not n.startswith("emb_")) == 21_785_568   # Inception-v3 trunk
     f, c = ENC.StandInImageEncoder(8)(torch.randn(2, 3, 64, 64))
     assert tuple(f.shape) == (2, 8, 17, 17) and tuple(c.shape) == (2, 8)
+
+
+def _rnn_vs_golden(dev, tol):
+    """f2: networks/rnn_encoder.py against the fixture generated from the reference's RNNEncoder (rnn_encoder.py:68-96)."""
+    from helpers import assert_close, load, probe, sub, T
+    RNN = importlib.import_module("attention-gan_amd.networks.rnn_encoder")
+    g = load("f2_rnn_encoder")
+    vocab, embdim, nhidden, B, Tn = (int(v) for v in g["dims"])
+    m = RNN.RNNEncoder(vocabsize=vocab, embdim=embdim, dropprob=0.0, nhidden=nhidden)
+    params = sub(g, "param/")
+    assert set(m.state_dict()) == set(params)
+    m.load_state_dict(params)
+    m = m.to(dev).train()
+    w, s = m(T(g["captions"]).to(dev), T(g["lengths"]))
+    assert_close(w, g["word_embs"], tol, "word_embs")
+    assert_close(s, g["sent_embs"], tol, "sent_embs")
+    ((w * probe(w.shape, 0.7).to(dev)).sum() + (s * probe(s.shape, 0.8).to(dev)).sum()).backward()
+    grads = sub(g, "gparam/")
+    assert set(grads) == {k for k, p in m.named_parameters()}
+    for k, p in m.named_parameters():
+        assert_close(p.grad, grads[k], tol, f"grad {k}")
+
+
+def test_rnn_encoder_vs_reference_golden_cpu():
+    _rnn_vs_golden("cpu", 1e-5)
 
 
 def test_batch_wire_format(tmp_path):
