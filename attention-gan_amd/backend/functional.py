@@ -216,9 +216,26 @@ def _repack_group(rng) -> None:
         e["cache"][e["key"]] = ((e["ptr"], e["tver"], _WEIGHT_EPOCH[0], rng[2]) + e["dims"], e["wk"], rng)
 
 
-def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None) -> Tensor:
-    cout, cin, kh, kw = w.shape
+_EFF_PREC = {}
+
+
+def effective_precision(g: L.ConvGeom) -> int:
+    """The arithmetic mode a gather geometry really runs in under the current precision setting (include/agan.h:
+    agan_conv_effective_prec): the 16-bit patch kernels take the 3x3 / 2x2-per-class / 4x4-s2 geometries, everything else is fp32."""
     prec = _PRECISION[0]
+    if prec == L.PREC_F32:
+        return prec
+    key = (prec, g.B, g.Cin, g.IH, g.IW, g.Cout, g.OH, g.OW, g.R, g.S, g.OS, g.SY, g.DY, g.OY[0], g.OY[1])
+    hit = _EFF_PREC.get(key)
+    if hit is None:
+        hit = _EFF_PREC[key] = int(L.load().agan_conv_effective_prec(byref(g), prec))
+    return hit
+
+
+def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None, prec: Optional[int] = None) -> Tensor:
+    cout, cin, kh, kw = w.shape
+    if prec is None:
+        prec = _PRECISION[0]
     key = (mode, prec)
     hit = cache.get(key) if cache is not None else None
     ptr = w.data_ptr()
@@ -275,15 +292,15 @@ def set_launch_observer(obs) -> None:
 
 
 def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "",
-            act: int = 0, lrelu_mask: Optional[Tensor] = None) -> None:
+            act: int = 0, lrelu_mask: Optional[Tensor] = None, prec: int = L.PREC_F32) -> None:
     lib = L.load()
-    nbytes = lib.agan_conv_gather_ws_bytes(byref(g), _PRECISION[0])
+    nbytes = lib.agan_conv_gather_ws_bytes(byref(g), prec)
     ws, wsp = _ws(nbytes, x)
     kt = ktable(g, x.device)
     obs = _OBSERVER[0]
     if obs is not None:
         obs.begin(kind, phase, g)
-    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), _PRECISION[0], act, _p(lrelu_mask), wsp, nbytes,
+    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), prec, act, _p(lrelu_mask), wsp, nbytes,
            _stream())
     if obs is not None:
         obs.end()
@@ -367,7 +384,8 @@ class _ConvFn(Function):
         gf, pf, gd, pd, (OH, OW) = conv_geoms(kind, B, Cin, H, W, Cout, kh)
         out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
-        _gather(x, packed_weight(w, pf, cache), b, gf, out, kind, "fwd", act)
+        pe = effective_precision(gf)
+        _gather(x, packed_weight(w, pf, cache, pe), b, gf, out, kind, "fwd", act, None, pe)
         if act == L.ACT_NONE:
             ctx.save_for_backward(x, w)
         else:                       # fused LeakyReLU: the backward needs the sign of the output
@@ -375,7 +393,7 @@ class _ConvFn(Function):
         ctx.kind, ctx.has_bias, ctx.cache, ctx.wdst, ctx.bdst, ctx.act = kind, bias is not None, cache, wdst, bdst, act
         ctx.handoff_out = handoff_out if act != L.ACT_NONE else None
         # the consumer can fold the producer's LeakyReLU backward into its dgrad epilogue on the fp32 MFMA path (> 4 channels)
-        ctx.handoff_in = handoff_in if (handoff_in is not None and _PRECISION[0] == L.PREC_F32 and Cin > 4) else None
+        ctx.handoff_in = handoff_in if (handoff_in is not None and Cin > 4) else None
         return out
 
     @staticmethod
@@ -422,15 +440,16 @@ class _ConvFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             mask = x if ctx.handoff_in is not None else None       # x is the producer's LeakyReLU output
-            _gather(dy, packed_weight(w, pd, ctx.cache), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask)
+            pe = effective_precision(gd)
+            _gather(dy, packed_weight(w, pd, ctx.cache, pe), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask, pe)
             if mask is not None:
                 ctx.handoff_in.masked = True
         return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv_fuses_activation(act: int, cout: int) -> bool:
-    """can conv2d apply `act` in its epilogue? (LeakyReLU on the fp32 MFMA path; include/agan.h: agan_conv_gather)"""
-    return act == L.ACT_LRELU and _PRECISION[0] == L.PREC_F32 and cout > 4
+    """can conv2d apply `act` in its epilogue? (LeakyReLU on the MFMA paths; include/agan.h: agan_conv_gather)"""
+    return act == L.ACT_LRELU and cout > 4
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, kind: str = "same", cache: Optional[dict] = None,
@@ -516,8 +535,10 @@ class _BnActFn(Function):
         groups = ctx.groups
         Bg = B // groups
         dx = torch.empty_like(x)
-        dgbuf, gacc, dg = _grad_out(ctx.gdst, g.shape, x)
-        dbbuf, bacc, db = _grad_out(ctx.bdst, b.shape, x)
+        # frozen affine parameters (a discriminator inside the generator update): the sums are still needed for dx, but they go
+        # to scratch, not into the owner's flat gradient buffer
+        dgbuf, gacc, dg = _grad_out(ctx.gdst if ctx.needs_input_grad[1] else None, g.shape, x)
+        dbbuf, bacc, db = _grad_out(ctx.bdst if ctx.needs_input_grad[2] else None, b.shape, x)
         if gacc != bacc:
             raise L.AganError("BatchNorm weight/bias gradient destinations out of step")
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(Bg, C, HW)

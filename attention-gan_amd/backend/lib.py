@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AGAN_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libagan_hip.so")   # AGAN_LIB: kernel A/B builds
 
 # enums of include/agan.h
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_BF16X6 = 0, 1, 2, 3, 4
+PRECISIONS = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x6": PREC_BF16X6}
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_4x4S2, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -38,6 +39,7 @@ _SIGNATURES = {
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "agan_conv_effective_prec": (c_int, [POINTER(ConvGeom), c_int]),
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),

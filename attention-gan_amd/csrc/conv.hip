@@ -786,17 +786,17 @@ size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int
     int ncls, K, N;
     if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
     if (prec == AGAN_PREC_F32) return (size_t)ncls * K * ((N + 31) / 32 * 32) * sizeof(float);
-    if (prec == AGAN_PREC_BF16X3) return (size_t)ncls * 2 * ((N + 31) / 32 * 32) * agan_round_up(K, 32) * sizeof(unsigned short);
+    if (prec_planes(prec) > 0) return patch_packed_weight_bytes(mode, cout, cin, kh, kw, prec);
     return 0;
 }
 
 int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int kh, int kw, int prec, void* stream) {
     int ncls, K, N;
     AGAN_REQUIRE(w && wkv, "pack_weight: null pointer");
-    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "pack_weight: precision mode %d not built", prec);
-    if (prec == AGAN_PREC_BF16X3) {
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "pack_weight: unknown precision mode %d", prec);
+    if (prec != AGAN_PREC_F32) {
         AGAN_REQUIRE(pack_dims(mode, cout, cin, kh, kw, ncls, K, N) == 0, "pack_weight: mode %d does not take %dx%d", mode, kh, kw);
-        return pack_weight_bf16x3(w, wkv, mode, cout, cin, kh, kw, as_stream(stream));
+        return pack_weight_patch(w, wkv, mode, cout, cin, kh, kw, prec, as_stream(stream));
     }
     float* wk = static_cast<float*>(wkv);
     AGAN_REQUIRE(pack_dims(mode, cout, cin, kh, kw, ncls, K, N) == 0, "pack_weight: mode %d does not take %dx%d", mode, kh, kw);
@@ -829,10 +829,18 @@ int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, in
     return check_launch("pack_weights");
 }
 
+int agan_conv_effective_prec(const agan_conv_geom* g, int prec) {
+    if (prec == AGAN_PREC_F32 || check_geom(g)) return AGAN_PREC_F32;
+    if (prec_planes(prec) == 0) return AGAN_PREC_F32;
+    return patch_supported(make_geom(g)) ? prec : AGAN_PREC_F32;
+}
+
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (check_geom(g)) return 0;
     const Geom gg = make_geom(g);
+    prec = agan_conv_effective_prec(g, prec);
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(gg)) return 0;
+    if (prec != AGAN_PREC_F32) return plan_patch_gather(gg, make_patch_plan(gg)).ws_bytes;
     return plan_gather(gg, prec).ws_bytes;
 }
 
@@ -856,14 +864,37 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     const float* wk = static_cast<const float*>(wkv);
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
-    AGAN_REQUIRE(act == AGAN_ACT_NONE || (act == AGAN_ACT_LRELU && prec == AGAN_PREC_F32 && gg->Cout > 4),
-                 "conv_gather: fused activation %d not available for this call (fp32 MFMA path, LeakyReLU only)", act);
-    AGAN_REQUIRE(!lrelu_mask || (prec == AGAN_PREC_F32 && gg->Cout > 4 && act == AGAN_ACT_NONE),
-                 "conv_gather: the LeakyReLU-derivative mask needs the fp32 MFMA path and no other activation");
+    AGAN_REQUIRE(act == AGAN_ACT_NONE || (act == AGAN_ACT_LRELU && gg->Cout > 4),
+                 "conv_gather: fused activation %d not available for this call (MFMA paths, LeakyReLU only)", act);
+    AGAN_REQUIRE(!lrelu_mask || (gg->Cout > 4 && act == AGAN_ACT_NONE),
+                 "conv_gather: the LeakyReLU-derivative mask needs an MFMA path and no other activation");
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
-    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_gather: precision mode %d not built in this version", prec);
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_gather: unknown precision mode %d", prec);
+    AGAN_REQUIRE(agan_conv_effective_prec(gg, prec) == prec,
+                 "conv_gather: precision mode %d does not take this geometry (agan_conv_effective_prec says which one does)", prec);
     const Geom g = make_geom(gg);
     hipStream_t st = as_stream(stream);
+    if (prec != AGAN_PREC_F32) {
+        const PatchPlan pp = make_patch_plan(g);
+        const PatchGather p = plan_patch_gather(g, pp);
+        if (p.ws_bytes > ws_bytes || (p.ws_bytes && !ws)) {
+            set_error("conv_gather: workspace %zu < %zu", ws_bytes, p.ws_bytes);
+            return AGAN_EWORKSPACE;
+        }
+        float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
+        timer_begin(st);
+        launch_patch_gather(in, wkv, bias, dst, g, pp, p, prec, act, lrelu_mask, st);
+        timer_end(st);
+        if (int e = check_launch("conv_gather/patch")) return e;
+        if (p.ksplit > 1) {
+            const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
+            const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
+                               bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask);
+            return check_launch("conv_gather/sum_slabs");
+        }
+        return AGAN_OK;
+    }
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {
         timer_begin(st);
         launch_gather_small_n(in, wk, bias, out, g, st);
@@ -877,8 +908,7 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     }
     float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
     timer_begin(st);
-    if (prec == AGAN_PREC_BF16X3) launch_gather_bf16x3(in, wkv, bias, dst, ktab, g, p, st);
-    else if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
+    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
     else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
     else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
     timer_end(st);
@@ -897,15 +927,22 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (check_geom(g)) return 0;
     const Geom gg = make_geom(g);
     // the larger of the two candidate paths (the small-N path is fp32-only; the caller does not pass the precision here)
-    const size_t a = plan_wgrad(gg, g->OS == 2).ws_bytes;
-    return small_n_wgrad_supported(gg) ? std::max(a, plan_wgrad_small_n(gg).ws_bytes) : a;
+    size_t a = plan_wgrad(gg, g->OS == 2).ws_bytes;
+    if (small_n_wgrad_supported(gg)) a = std::max(a, plan_wgrad_small_n(gg).ws_bytes);
+    if (patch_supported(gg)) {
+        const PatchPlan pp = make_patch_plan(gg);
+        a = std::max({a, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16).ws_bytes, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16X6).ws_bytes});
+    }
+    return a;
 }
 
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
                     int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
-    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec == AGAN_PREC_BF16X3, "conv_wgrad: precision mode %d not built in this version", prec);
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
+    // geometries the patch kernels do not take run on the fp32 MFMA kernels (the operands are fp32 activations either way)
+    if (prec != AGAN_PREC_F32 && !patch_supported(make_geom(gg))) prec = AGAN_PREC_F32;
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
     const bool up = pack_mode == AGAN_PACK_UP_FWD;
@@ -914,6 +951,28 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
     hipStream_t st = as_stream(stream);
+    if (prec != AGAN_PREC_F32) {
+        const PatchPlan pp = make_patch_plan(g);
+        const PatchWgrad p = plan_patch_wgrad(g, pp, prec);
+        if (p.ws_bytes > ws_bytes || !ws) {
+            set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, p.ws_bytes);
+            return AGAN_EWORKSPACE;
+        }
+        float* wsf = static_cast<float*>(ws);
+        float* reduced = p.psplit > 1 ? wsf + p.slab * p.psplit : wsf;
+        timer_begin(st);
+        launch_patch_wgrad(x, dy, wsf, g, pp, p, prec, st);
+        timer_end(st);
+        if (int e = check_launch("conv_wgrad/patch")) return e;
+        if (p.psplit > 1) {
+            const size_t n = (size_t)p.ncls * g.Cout * p.Kp;
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, p.psplit, n,
+                               p.slab, (const float*)nullptr, 1, 1, reduced, 0);
+            if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
+        }
+        launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, up, pp, p, accumulate, st);
+        return check_launch("conv_wgrad/unpack");
+    }
     if (prec == AGAN_PREC_F32 && !up && small_n_wgrad_supported(g)) {
         const SmallWgradPlan sp = plan_wgrad_small_n(g);
         if (sp.ws_bytes > ws_bytes || !ws) {
@@ -939,15 +998,14 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     // where the (reduced) [cls][cout][K] result lands: dw itself for a direct conv, a scratch slab before the tap combine.
     // Under `accumulate` an unsplit direct conv also goes through one scratch slab so that the sum pass can add to dw.
     // an unsplit direct conv accumulates in its own epilogue (f32 kernels); every other case goes through the slab sum
-    const int acc_in_kernel = (accumulate && !up && p.psplit == 1 && prec == AGAN_PREC_F32) ? 1 : 0;
+    const int acc_in_kernel = (accumulate && !up && p.psplit == 1) ? 1 : 0;
     const bool via_sum = p.psplit > 1 || (accumulate && !up && !acc_in_kernel);
     float* reduced = up ? wsf + (p.psplit > 1 ? p.slab * p.psplit : 0) : dw;
     float* part = via_sum ? wsf : reduced;
     dim3 grid(p.itiles, p.jtiles, p.ncls * p.psplit);
 #define AGAN_WG(BI, BJ) hipLaunchKernelGGL((conv_wgrad_f32_kernel<BI, BJ>), grid, dim3(256), 0, st, x, dy, part, ktab, g, p.psplit, p.pchunk, p.slab, acc_in_kernel)
     timer_begin(st);
-    if (prec == AGAN_PREC_BF16X3) launch_wgrad_bf16x3(x, dy, part, ktab, g, p, st);
-    else if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
+    if (p.bi == 128 && p.bj == 128) AGAN_WG(128, 128);
     else if (p.bi == 128) AGAN_WG(128, 64);
     else if (p.bj == 128) AGAN_WG(64, 128);
     else AGAN_WG(64, 64);

@@ -240,11 +240,47 @@ bool small_n_wgrad_supported(const Geom& g);
 SmallWgradPlan plan_wgrad_small_n(const Geom& g);
 void launch_wgrad_small_n(const float* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st);
 
-// AGAN_PREC_BF16X3 kernels (conv_bf16.hip)
-int pack_weight_bf16x3(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, hipStream_t st);
-void launch_gather_bf16x3(const float* in, const void* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
-                          const GatherPlan& p, hipStream_t st);
-void launch_wgrad_bf16x3(const float* x, const float* dy, float* part, const int2* ktab, const Geom& g, const WgradPlan& p, hipStream_t st);
+// ---- patch-resident 16-bit MFMA kernels (conv_patch.hip): AGAN_PREC_BF16 / F16 / BF16X3 / BF16X6 ------------------------------
+// taps of the GATHER geometry a pack mode is used with (R x S per class, input step SY): a 3x3 forward conv is the stride-1
+// 'same' conv, a 4x4 one the stride-2 'down' conv (the only two the layer factory builds)
+__host__ __device__ inline void pack_taps(int mode, int kh, int kw, int& R, int& S, int& SY) {
+    switch (mode) {
+        case AGAN_PACK_DGRAD_4x4S2: case AGAN_PACK_UP_FWD: R = S = 2; SY = 1; return;
+        case AGAN_PACK_UP_DGRAD: R = S = 4; SY = 2; return;
+        default: R = kh; S = kw; SY = (kh == 4) ? 2 : 1; return;
+    }
+}
+struct PatchPlan {
+    int twl, thl;                       // log2 of the tile's width / height in lattice points; images per tile = 128 >> (twl + thl)
+    int tiles_x, tiles_y, tiles_b, mtiles;
+    int PW, PH, PHW, PP;                // patch width, height, positions per image, positions per tile
+    int NPH, NT, IS;                    // phases (input parity sub-lattices), taps per phase, input step
+    int nchunks, nstages, nsteps;       // 32-channel chunks; stages = chunks x phases; k-steps = stages x taps x 2
+    int tapoff[9];                      // LDS byte offset of each tap
+    int base_y[2][2], base_x[2][2];     // [output parity class][phase parity]: input coordinate of patch row/col 0 = IS * tile origin + base
+    FastDiv dPP, dPHW, dPW;
+};
+struct PatchGather {
+    int bn, ntiles, ncls, ksplit, stages_per_split;
+    size_t slab, ws_bytes;
+};
+struct PatchWgrad {
+    int bj, jtiles, ncls, psplit, tiles_per_split, Kp;
+    size_t slab, ws_bytes;
+};
+int prec_planes(int prec);
+PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec);
+void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
+                        hipStream_t st);
+void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,
+                               int accumulate, hipStream_t st);
+bool patch_supported(const Geom& g);
+PatchPlan make_patch_plan(const Geom& g);
+PatchGather plan_patch_gather(const Geom& g, const PatchPlan& pp);
+size_t patch_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
+int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, hipStream_t st);
+void launch_patch_gather(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp,
+                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st);
 
 }  // namespace conv
 }  // namespace agan

@@ -1,0 +1,784 @@
+// Patch-resident implicit-GEMM convolution on the 16-bit matrix cores of gfx950 (v_mfma_f32_32x32x16_{bf16,f16}).
+//
+// Modes (include/agan.h):  AGAN_PREC_BF16 / AGAN_PREC_F16  one rounded plane, one MFMA per product;
+//                          AGAN_PREC_BF16X3               two bf16 planes (hi, lo), 3 MFMAs per product (~2^-16 per product);
+//                          AGAN_PREC_BF16X6               three bf16 planes (hi, mid, lo = 24 mantissa bits), 6 MFMAs per
+//                                                         product: fp32-grade products at 2.67x the fp32-MFMA rate.
+// HBM tensors stay NCHW fp32; fp32 accumulate always.
+//
+// Why a new structure instead of the k-table gather of conv.hip: the fp32 kernel fetches every im2col element from L1/L2 --
+// a 3x3 layer reads each input value nine times -- which is what capped the first split-precision kernel (conv_bf16.hip)
+// at 1.2x.  Here a workgroup owns a 2-D tile of 128 output pixels (32 wide when the image allows it) and stages the INPUT
+// PATCH of that tile (tile + halo) for 32 channels in LDS ONCE per stage, already converted to 16-bit planes and laid out
+// [position][channel]; the reduction index is reordered to (channel chunk, phase, tap, channel), so the MFMA operand of a
+// pixel for tap (r, s) and 8 consecutive channels is ONE aligned ds_read_b128 at
+//        patch[(y + r) * PW + (x + s)][8 channels]
+// -- no im2col tile is ever built, no per-element address work, and a 3x3 layer loads 1.6 instead of 9 values per pixel
+// and channel.  Position rows are 80 bytes (32 x 16 bit + 16 pad): an odd multiple of 16 B, so the 16-lane groups of
+// ds_read_b128 (lanes = 32 consecutive pixels of a tile row) and the 8-lane groups of ds_write_b128 are conflict-free.
+// Stride-2 convolutions (conv4x4 s2, and the 4x4 s2 data gradient of the upsample conv) run as FOUR PHASES -- the four parity
+// sub-lattices of the input, each a 2x2-tap stride-1 problem on its own patch -- so LDS reads stay unit-stride.
+//
+// Weights never touch LDS: agan_pack_weight lays them out [class][k-step][plane][cout][16] in 16-bit, i.e. the 32 x 16
+// operand block of a wave for one k-step is 1 KB contiguous and is fetched (L2-resident, shared by every workgroup) by
+// one buffer_load_b128 per lane straight into the MFMA operand registers, two k-steps ahead of its use.  The K loop therefore
+// synchronises only where the patch changes (every 8 or 18 k-steps), not per k-step.
+//
+// Accumulators are D[cout][pixel] like conv.hip (weights are the A operand): a register holds 32 consecutive pixels of one
+// output channel, NCHW stores are 128-byte coalesced.  Each of the 4 waves owns 32 output channels x all 128 pixels (BN = 128),
+// so pixel fragments are shared through LDS and weight fragments are not duplicated between waves.
+#include "conv_common.h"
+
+using namespace agan;
+using namespace agan::conv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCH = 32;             // channels per stage
+constexpr int kPosBytes = 80;       // LDS bytes per patch position and plane
+constexpr int kMaxPos = 320;        // positions a patch may have (host checks)
+constexpr int kPlaneBytes = kMaxPos * kPosBytes;
+constexpr int kItems = (kMaxPos * (kCH / 8) + 255) / 256;     // (position, channel octet) staging items per thread
+
+__device__ __forceinline__ u32x4 buf_load_u4s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// ---- fp32 -> 16-bit planes ----------------------------------------------------------------------------------------
+// ET 0 = bf16, 1 = f16.  NPL planes: plane 0 = round-to-nearest of x (one plane) or its leading bits, the further planes the
+// exactly representable remainders (x - hi is exact in fp32), so hi (+ mid) + lo carries 16 / 24 mantissa bits.
+template <int ET>
+__device__ __forceinline__ unsigned pack2_rne(float a, float b) {
+    if (ET == 0) {
+        f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    } else {
+        f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    }
+}
+__device__ __forceinline__ unsigned pack_top16(unsigned ua, unsigned ub) {       // (ua >> 16) | (ub & 0xFFFF0000)
+    return __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+}
+template <int ET, int NPL>
+__device__ __forceinline__ void split_pack2(float a, float b, unsigned (&pl)[NPL]) {
+    if (NPL == 1) {
+        pl[0] = pack2_rne<ET>(a, b);
+    } else {
+        // truncating splits: every remainder is exact, |x - sum of planes| < 2^-(8*NPL) |x|
+        const unsigned a0 = __float_as_uint(a) & 0xFFFF0000u, b0 = __float_as_uint(b) & 0xFFFF0000u;
+        pl[0] = pack_top16(a0, b0);
+        const float ra = a - __uint_as_float(a0), rb = b - __uint_as_float(b0);
+        if (NPL == 2) {
+            pl[1] = pack2_rne<0>(ra, rb);
+        } else {
+            const unsigned a1 = __float_as_uint(ra) & 0xFFFF0000u, b1 = __float_as_uint(rb) & 0xFFFF0000u;
+            pl[1] = pack_top16(a1, b1);
+            pl[NPL - 1] = pack2_rne<0>(ra - __uint_as_float(a1), rb - __uint_as_float(b1));
+        }
+    }
+}
+
+template <int ET>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if (ET == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// products of an NPL-plane split, smallest terms first:  1: hh   2: lh hl hh   3: lh hl mm mh hm hh  (w plane, a plane)
+template <int ET, int NPL>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&w)[NPL], const u32x4 (&a)[NPL], f32x16 c) {
+    if (NPL == 1) return mfma16<ET>(w[0], a[0], c);
+    if (NPL == 2) {
+        c = mfma16<0>(w[1], a[0], c);
+        c = mfma16<0>(w[0], a[1], c);
+        return mfma16<0>(w[0], a[0], c);
+    }
+    c = mfma16<0>(w[NPL - 1], a[0], c);
+    c = mfma16<0>(w[0], a[NPL - 1], c);
+    c = mfma16<0>(w[1], a[1], c);
+    c = mfma16<0>(w[1], a[0], c);
+    c = mfma16<0>(w[0], a[1], c);
+    return mfma16<0>(w[0], a[0], c);
+}
+
+// ================================================================================================
+// forward / data-gradient kernel
+// ================================================================================================
+template <int ET, int NPL, int BN, int NT>
+__global__ __launch_bounds__(256) void conv_patch_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wk,
+                                                         const float* __restrict__ bias, float* __restrict__ out, const Geom g,
+                                                         const PatchPlan pp, const int ksplit, const int stages_per_split,
+                                                         const size_t slab, const int act, const float* __restrict__ lrelu_mask) {
+    constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;        // each wave: 32 output channels x TM x 32 pixels
+    constexpr int SPS = 2 * NT;                                   // k-steps (16 channels of one tap) per stage
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NPL * kPlaneBytes];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- tile of this workgroup (XCD-aware order as in conv.hip: channel tile fastest, then parity class, pixel tile, K split) ----
+    int mt, nt, cls, split;
+    {
+        const int ncls = gridDim.z / ksplit, mtiles = gridDim.x, ntiles = gridDim.y;
+        int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * (int)gridDim.z);
+        nt = F % ntiles; F /= ntiles;
+        cls = F % ncls;  F /= ncls;
+        mt = F % mtiles; split = F / mtiles;
+    }
+    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int n0 = nt * BN;
+    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+    const int twl = pp.twl, thl = pp.thl;
+    const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+    const int ihw = g.IH * g.IW;
+    const int stage_beg = split * stages_per_split, stage_end = min(pp.nstages, stage_beg + stages_per_split);
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const size_t wbytes_cls = (size_t)pp.nsteps * NPL * g.Nld * 32;                 // bytes of one class's packed weights
+    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)cls * wbytes_cls, wbytes_cls);
+
+    // ---- staging items: (patch position, channel octet) -> registers hold what does not change between stages -------------
+    int it_iy[kItems], it_ix[kItems], it_cb[kItems];      // input row/col of the position for phase offset 0; (b*Cin + oct*8)*ihw or -1
+    unsigned it_lds[kItems];
+    int it_oct[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int e = tid + i * 256;
+        const int oct = pp.dPP.div(e), p = e - oct * pp.PP;
+        const int pb = pp.dPHW.div(p), rem = p - pb * pp.PHW;
+        const int j = pp.dPW.div(rem), ii = rem - j * pp.PW;
+        const int b = tb0 + pb;
+        const bool ok = (oct < kCH / 8) & (b < g.B);
+        it_iy[i] = pp.IS * (ty0 + j);
+        it_ix[i] = pp.IS * (tx0 + ii);
+        it_cb[i] = ok ? (b * g.Cin + oct * 8) * ihw : -1;
+        it_oct[i] = oct;
+        it_lds[i] = (unsigned)(p * kPosBytes + oct * 16);
+    }
+    float sreg[kItems][8];
+
+    auto load_patch = [&](int stage) {
+        const int chunk = stage / pp.NPH, ph = stage - chunk * pp.NPH;
+        const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
+        const int c0 = chunk * kCH;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const int iy = it_iy[i] + by, ix = it_ix[i] + bx;
+            const bool ok = (it_cb[i] >= 0) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            const unsigned voff = ok ? (unsigned)(it_cb[i] + c0 * ihw + iy * g.IW + ix) * 4u : kOOB;
+            const int nrem = g.Cin - c0 - it_oct[i] * 8;                    // channels of this octet that exist
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            if (it_oct[i] < kCH / 8) {          // (items past the patch decode to octet >= 4: nothing to store)
+                u32x4 v[NPL];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned pl[NPL];
+                    split_pack2<ET, NPL>(sreg[i][2 * c], sreg[i][2 * c + 1], pl);
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(patch + q * kPlaneBytes + it_lds[i]) = v[q];
+            }
+        }
+    };
+
+    // ---- MFMA operand addresses -----------------------------------------------------------------------------------------------
+    unsigned lbase[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        lbase[t] = (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes + lh * 16);
+    }
+    // byte offset inside a [Nld][16] weight block (rows past Nld only feed accumulator rows that are never stored: clamp)
+    const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    const unsigned wstep = (unsigned)(NPL * g.Nld * 32);                         // bytes per k-step
+    u32x4 wf[2][NPL];
+    const int qlast = pp.nsteps - 1;
+    auto load_w = [&](int slot, int q) {       // (the scalar offset is not range-checked by the buffer unit: clamp the step)
+        const unsigned so = (unsigned)min(q, qlast) * wstep;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) wf[slot][p] = buf_load_u4s(rwk, wlane, so + (unsigned)(p * g.Nld * 32));
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (stage_beg < stage_end) {
+        int q = stage_beg * SPS;
+        load_w(0, q);
+        load_w(1, q + 1);
+        load_patch(stage_beg);
+        store_patch();
+        __syncthreads();
+        for (int stage = stage_beg; stage < stage_end; ++stage) {
+            const bool more = stage + 1 < stage_end;
+            if (more) load_patch(stage + 1);
+#pragma unroll
+            for (int u = 0; u < SPS; ++u) {
+                const int t = u >> 1, cb = u & 1;
+                u32x4 w[NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) w[p] = wf[u & 1][p];
+                load_w(u & 1, q + 2);                                   // two k-steps ahead (past the end: unused / zero)
+                ++q;
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    u32x4 a[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p)
+                        a[p] = *reinterpret_cast<const u32x4*>(patch + p * kPlaneBytes + lbase[m] + pp.tapoff[t] + cb * 32);
+                    acc[m] = mfma_split<ET, NPL>(w, a, acc[m]);
+                }
+            }
+            __syncthreads();                  // every wave is done reading this stage's patch
+            if (more) {
+                store_patch();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ------------------------------
+    const size_t ohw = (size_t)g.OH * g.OW;
+    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const bool add_bias = (bias != nullptr) && (ksplit == 1);
+    const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);
+    const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+        const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+        const unsigned pixoff = (unsigned)(b * g.Cout) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[t][r];
+            if (add_bias) v += bias[min(n, g.Cout - 1)];
+            if (lrelu) v = v > 0.f ? v : 0.2f * v;
+            const unsigned off = (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB;
+            if (masked) v = buf_load(rmask, off) > 0.f ? v : 0.2f * v;
+            buf_store(rout, off, v);
+        }
+    }
+}
+
+// ================================================================================================
+// weight gradient:  dw[cls][cout][(phase, tap, ci)] = sum over the class lattice  dy[pixel][cout] * x[pixel + tap][ci]
+// ================================================================================================
+// The contraction runs over pixels, 16 consecutive pixels of a tile row per MFMA.  Both operands are staged exactly like the
+// gather kernel's patch -- [position][channel] 16-bit planes, written with ds_write_b128 from coalesced NCHW loads -- the input
+// as the tile's patch (tile + halo, 32 channels), dy as the tile itself (BJ output channels); the MFMA wants them
+// [channel][8 consecutive pixels], which is what gfx950's transposing LDS read delivers: ds_read_b64_tr_b16 hands lane i of a
+// 16-lane group column i of a 4-pixel x 16-channel block, so two of them are one operand fragment and a tap is, again, just
+// a constant offset into the patch (cdna_hip_programming.md T10).  One workgroup owns (cout tile, 32-channel chunk, parity
+// class, input phase, pixel split) and keeps all taps of its chunk in accumulators: D[cout][channel] per tap, i.e. the result
+// is written as dw[cout][tap][ci] rows of 32 consecutive channels and put into OIHW order by the unpack pass.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ds_read_tr8(const unsigned char* lds, unsigned off0, unsigned off1) {
+    // 8 pixels x (this lane's channel): the 4-pixel block at off0 and the next one at off1
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off1));
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    u32x4 r = {(unsigned)ua, (unsigned)(ua >> 32), (unsigned)ub, (unsigned)(ub >> 32)};
+    return r;
+}
+
+template <int BJ> struct WgCfg {
+    static constexpr int kYRow = BJ == 128 ? 336 : 144;       // bytes per pixel of the dy image (BJ x 16 bit + pad; odd multiple of 16 mod 256)
+    static constexpr int kYPlane = 128 * kYRow;
+    static constexpr int kYItems = 128 * (BJ / 8) / 256;      // (pixel, cout octet) staging items per thread
+};
+
+template <int ET, int NPL, int BJ, int NT>
+__global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dst,
+                                                               const Geom g, const PatchPlan pp, const int psplit, const int tiles_per_split,
+                                                               const size_t slab) {
+    using C = WgCfg<BJ>;
+    constexpr int WJ = BJ / 32;                // waves along output channels
+    constexpr int WT = 4 / WJ;                 // waves sharing the taps of a cout block
+    constexpr int TPW = (NT + WT - 1) / WT;    // taps per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * (kPlaneBytes + C::kYPlane)];
+    unsigned char* const xs = lds;
+    unsigned char* const ys = lds + NPL * kPlaneBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wj = wave % WJ, wt = wave / WJ;
+    // workgroup -> (cout tile, chunk x phase, class, pixel split); F = (((split * classes + class) * stages + stage) * jtiles + cout tile:
+    // the cout tiles of one (pixel range, stage) share the patch, the stages share dy -- neighbours in F run on one XCD
+    int jt, stage, cls, split;
+    {
+        const int jtiles = gridDim.x, nst = gridDim.y, ncls = gridDim.z / psplit;
+        int F = xcd_contiguous(linear_block_id(), jtiles * nst * (int)gridDim.z);
+        jt = F % jtiles; F /= jtiles;
+        stage = F % nst; F /= nst;
+        cls = F % ncls;  split = F / ncls;
+    }
+    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int chunk = stage / pp.NPH, ph = stage - chunk * pp.NPH;
+    const int j0 = jt * BJ, c0 = chunk * kCH;
+    const int twl = pp.twl, thl = pp.thl;
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int tile_beg = split * tiles_per_split, tile_end = min(pp.mtiles, tile_beg + tiles_per_split);
+
+    // ---- staging items (tile independent parts) ----
+    int xi_j[kItems], xi_i[kItems], xi_b[kItems], xi_oct[kItems];
+    unsigned xi_lds[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int e = tid + i * 256;
+        const int oct = pp.dPP.div(e), p = e - oct * pp.PP;
+        const int pb = pp.dPHW.div(p), rem = p - pb * pp.PHW;
+        xi_j[i] = pp.dPW.div(rem);
+        xi_i[i] = rem - xi_j[i] * pp.PW;
+        xi_b[i] = pb;
+        xi_oct[i] = oct;
+        xi_lds[i] = (unsigned)(p * kPosBytes + oct * 16);
+    }
+    float xr[kItems][8], yr[C::kYItems][8];
+
+    auto load_tile = [&](int mt) {
+        const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+        const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const int b = tb0 + xi_b[i];
+            const int iy = pp.IS * (ty0 + xi_j[i]) + by, ix = pp.IS * (tx0 + xi_i[i]) + bx;
+            const bool ok = (xi_oct[i] < kCH / 8) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            const unsigned voff = ok ? (unsigned)((b * g.Cin + c0 + xi_oct[i] * 8) * ihw + iy * g.IW + ix) * 4u : kOOB;
+            const int nrem = g.Cin - c0 - xi_oct[i] * 8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xr[i][c] = buf_load_s(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+        }
+#pragma unroll
+        for (int i = 0; i < C::kYItems; ++i) {
+            const int e = tid + i * 256;
+            const int l = e & 127, oct = e >> 7;
+            const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+            const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+            const bool ok = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+            const int n = j0 + oct * 8;
+            const unsigned voff = ok ? (unsigned)((b * g.Cout + n) * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kOOB;
+            const int nrem = g.Cout - n;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) yr[i][c] = buf_load_s(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * 4u);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            if (xi_oct[i] < kCH / 8) {
+                u32x4 v[NPL];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned pl[NPL];
+                    split_pack2<ET, NPL>(xr[i][2 * c], xr[i][2 * c + 1], pl);
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(xs + q * kPlaneBytes + xi_lds[i]) = v[q];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::kYItems; ++i) {
+            const int e = tid + i * 256;
+            const int l = e & 127, oct = e >> 7;
+            u32x4 v[NPL];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned pl[NPL];
+                split_pack2<ET, NPL>(yr[i][2 * c], yr[i][2 * c + 1], pl);
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(ys + q * C::kYPlane + l * C::kYRow + oct * 16) = v[q];
+        }
+    };
+
+    // ---- transposed-read lane addresses: 16-lane group gq reads pixels 8*(gq>>1) + 4*e + q (q = (lane&15)>>2) for the 16 channels
+    //      16*(gq&1) + ..., lane (lane&3) supplying columns 4*(lane&3)..+3 of row q
+    const int gq = lane >> 4, li = lane & 15, rq = li >> 2, cp = li & 3;
+    const int lpix = 8 * (gq >> 1) + rq;                                         // this lane's pixel within the 16 of a step (first block)
+    const unsigned xcol = (unsigned)((16 * (gq & 1) + 4 * cp) * 2);
+    const unsigned ylane = (unsigned)(lpix * C::kYRow + (wj * 32 + 16 * (gq & 1) + 4 * cp) * 2);
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (tile_beg < tile_end) {
+        load_tile(tile_beg);
+        store_tile();
+        __syncthreads();
+        const int TW = 1 << twl;
+        const int nsteps = 8;                                     // 128 pixels / 16
+        for (int mt = tile_beg; mt < tile_end; ++mt) {
+            const bool more = mt + 1 < tile_end;
+            if (more) load_tile(mt + 1);
+            for (int kk = 0; kk < nsteps; ++kk) {
+                // 16 consecutive lattice points of the tile: l = 16*kk .. 16*kk+15  (a tile row holds 1, 2, 4 ... of them; tiles
+                // narrower than 16 wrap into the next row / image, which the position arithmetic below follows per 4-pixel block)
+                const int l0 = kk * 16;
+                u32x4 a[NPL];
+                {
+                    const unsigned yo = ylane + (unsigned)(l0 * C::kYRow);
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) a[p] = ds_read_tr8(ys + p * C::kYPlane, yo, yo + 4 * C::kYRow);
+                }
+                // patch positions of this lane's two 4-pixel blocks (a block never straddles a tile row: rows are >= 4 wide)
+                unsigned xo[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int l = l0 + lpix + 4 * e;
+                    const int tx = l & (TW - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+                    xo[e] = xcol + (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes);
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int tap = wt * TPW + t;
+                    if (tap < NT) {
+                        u32x4 b[NPL];
+#pragma unroll
+                        for (int p = 0; p < NPL; ++p)
+                            b[p] = ds_read_tr8(xs + p * kPlaneBytes, xo[0] + (unsigned)pp.tapoff[tap], xo[1] + (unsigned)pp.tapoff[tap]);
+                        acc[t] = mfma_split<ET, NPL>(a, b, acc[t]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- D[cout][channel of the chunk] per tap -> dst[split][cls][cout][kprime], kprime = ((chunk*NPH + ph)*NT + tap)*32 + ci ----
+    const int Kp = pp.nstages * NT * kCH;
+    float* o = dst + (size_t)split * slab + (size_t)cls * g.Cout * Kp;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)g.Cout * Kp * sizeof(float));
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = wt * TPW + t;
+        if (tap >= NT) break;
+        const int kcol = (stage * NT + tap) * kCH + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = j0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            buf_store(ro, n < g.Cout ? (unsigned)(n * Kp + kcol) * 4u : kOOB, acc[t][r]);
+        }
+    }
+}
+
+// dw[cout][ci][kh][kw] (OIHW) from the reduced [cls][cout][K'] result; UP mode folds the 4 classes' 2x2 taps back into 3x3.
+// K' index = ((chunk * NPH + phase) * NT + tap) * 32 + ci%32.
+__global__ __launch_bounds__(256) void unpack_patch_wgrad_kernel(const float* __restrict__ red, float* __restrict__ dw, int cout, int cin,
+                                                                 int kh, int kw, int up, int NPH, int NT, int Kp, int accumulate) {
+    const size_t total = (size_t)cout * cin * kh * kw;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int s = (int)(e % kw);
+        size_t t = e / kw;
+        const int r = (int)(t % kh); t /= kh;
+        const int ci = (int)(t % cin), co = (int)(t / cin);
+        const int chunk = ci / kCH, cc = ci - chunk * kCH;
+        float v = 0.f;
+        if (!up) {
+            int ph = 0, tap;
+            if (NPH == 1) tap = r * kw + s;
+            else { ph = (r & 1) * 2 + (s & 1); tap = (r >> 1) * (kw / 2) + (s >> 1); }
+            v = red[(size_t)co * Kp + ((chunk * NPH + ph) * NT + tap) * kCH + cc];
+        } else {
+            // 3x3 tap (r, s) was folded into tap (rr, ss) of class (py, px) whenever up_fwd_taps(py, rr) covers r and (px, ss) covers s
+            for (int py = 0; py < 2; ++py)
+                for (int rr = 0; rr < 2; ++rr) {
+                    int rl, rh;
+                    up_fwd_taps(py, rr, rl, rh);
+                    if (r < rl || r > rh) continue;
+                    for (int px = 0; px < 2; ++px)
+                        for (int ss = 0; ss < 2; ++ss) {
+                            int sl, sh;
+                            up_fwd_taps(px, ss, sl, sh);
+                            if (s < sl || s > sh) continue;
+                            v += red[((size_t)(py * 2 + px) * cout + co) * Kp + (chunk * NT + rr * 2 + ss) * kCH + cc];
+                        }
+                }
+        }
+        dw[e] = accumulate ? dw[e] + v : v;
+    }
+}
+
+// ================================================================================================
+// weight packing: OIHW -> [class][k-step][plane][Nld][16] 16-bit; k-step = ((chunk * NPH + phase) * NT + tap) * 2 + half
+// ================================================================================================
+template <int ET, int NPL>
+__global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout,
+                                                                int cin, int kh, int kw, int ncls, int Kin, int R, int S, int Nld,
+                                                                const PatchPlan pp) {
+    // one thread per (class, step, n, pair of channels)
+    const size_t total = (size_t)ncls * pp.nsteps * Nld * 8;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int j2 = (int)(e & 7);
+        size_t t = e >> 3;
+        const int n = (int)(t % Nld); t /= Nld;
+        const int q = (int)(t % pp.nsteps), cls = (int)(t / pp.nsteps);
+        const int half = q & 1, tq = q >> 1;
+        const int tap = tq % pp.NT, sq = tq / pp.NT, ph = sq % pp.NPH, chunk = sq / pp.NPH;
+        int r, s;
+        if (pp.IS == 1) { r = tap / S; s = tap - r * S; }
+        else { const int s2 = S / 2; r = 2 * (tap / s2) + (ph >> 1); s = 2 * (tap % s2) + (ph & 1); }
+        float v[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ci = chunk * kCH + half * 16 + j2 * 2 + c;
+            v[c] = ci < Kin / (R * S) ? packed_weight_value(w, mode, cls, (ci * R + r) * S + s, n, cout, cin, kh, kw) : 0.f;
+        }
+        unsigned pl[NPL];
+        split_pack2<ET, NPL>(v[0], v[1], pl);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+            reinterpret_cast<unsigned*>(wk)[((((size_t)cls * pp.nsteps + q) * NPL + p) * Nld + n) * 8 + j2] = pl[p];
+    }
+}
+
+template <int ET, int NPL, int BN>
+void launch_nt(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,
+               int act, const float* mask, hipStream_t st) {
+    dim3 grid(pp.mtiles, p.ntiles, p.ncls * p.ksplit);
+    const unsigned short* w = static_cast<const unsigned short*>(wk);
+    if (pp.NT == 9)
+        hipLaunchKernelGGL((conv_patch_kernel<ET, NPL, BN, 9>), grid, dim3(256), 0, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask);
+    else
+        hipLaunchKernelGGL((conv_patch_kernel<ET, NPL, BN, 4>), grid, dim3(256), 0, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask);
+}
+template <int ET, int NPL>
+void launch_bn(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,
+               int act, const float* mask, hipStream_t st) {
+    if (p.bn == 128) launch_nt<ET, NPL, 128>(in, wk, bias, dst, g, pp, p, act, mask, st);
+    else if (p.bn == 64) launch_nt<ET, NPL, 64>(in, wk, bias, dst, g, pp, p, act, mask, st);
+    else launch_nt<ET, NPL, 32>(in, wk, bias, dst, g, pp, p, act, mask, st);
+}
+
+template <int ET, int NPL, int BJ>
+void launch_wg_nt(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st) {
+    dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
+    if (pp.NT == 9)
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab);
+    else
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab);
+}
+
+inline int pow2ceil_log(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+namespace agan {
+namespace conv {
+
+int prec_planes(int prec) {
+    switch (prec) {
+        case AGAN_PREC_BF16: case AGAN_PREC_F16: return 1;
+        case AGAN_PREC_BF16X3: return 2;
+        case AGAN_PREC_BF16X6: return 3;
+    }
+    return 0;
+}
+
+// Can the patch kernels run this geometry?  (taps 2x2 / 3x3 per phase, images of at least 4x4 lattice points, tensors < 2^30)
+bool patch_supported(const Geom& g) {
+    if (g.Cout <= 4) return false;                                    // <= 4 output channels: the vector-ALU kernels (conv_small.hip)
+    if (g.SY == 1) {
+        if (!((g.R == 3 && g.S == 3) || (g.R == 2 && g.S == 2))) return false;
+        if (g.DY != 1 && g.DY != -1) return false;
+    } else if (g.SY == 2) {
+        if (!(g.R == 4 && g.S == 4 && g.DY == 1)) return false;
+    } else {
+        return false;
+    }
+    const PatchPlan pp = make_patch_plan(g);
+    return pp.PP <= kMaxPos && pp.twl >= 2;        // (the weight gradient reads 4-pixel blocks that must not straddle a tile row)
+}
+
+PatchPlan make_patch_plan(const Geom& g) {
+    PatchPlan pp;
+    memset(&pp, 0, sizeof(pp));
+    // 2-D tile of 128 lattice points: as wide as the image up to 32, then rows, then images
+    pp.twl = std::min(5, pow2ceil_log(g.OWs));
+    pp.thl = std::min(7 - pp.twl, pow2ceil_log(g.OHs));
+    const int TW = 1 << pp.twl, TH = 1 << pp.thl, TB = 128 >> (pp.twl + pp.thl);
+    pp.tiles_x = cdiv(g.OWs, TW);
+    pp.tiles_y = cdiv(g.OHs, TH);
+    pp.tiles_b = cdiv(g.B, TB);
+    pp.mtiles = pp.tiles_x * pp.tiles_y * pp.tiles_b;
+    pp.IS = g.SY;
+    int rows, cols;        // taps per phase
+    if (g.SY == 1) { pp.NPH = 1; rows = g.R; cols = g.S; }
+    else { pp.NPH = 4; rows = g.R / 2; cols = g.S / 2; }
+    pp.NT = rows * cols;
+    pp.PH = TH + rows - 1;
+    pp.PW = TW + cols - 1;
+    pp.PHW = pp.PH * pp.PW;
+    pp.PP = TB * pp.PHW;
+    // input coordinate of patch row j:  IS * (ty0 + j) + base_y[class parity][phase parity]
+    const int dmin = g.SY == 1 ? std::min(0, (g.R - 1) * g.DY) : 0;
+    for (int par = 0; par < 2; ++par)
+        for (int ph = 0; ph < 2; ++ph) {
+            const int oy = par ? g.OY1 : g.OY0;
+            pp.base_y[par][ph] = pp.base_x[par][ph] = (g.SY == 1 ? dmin : ph) + oy;
+        }
+    for (int t = 0; t < pp.NT; ++t) {
+        const int r = t / cols, s = t - r * cols;
+        const int ro = g.SY == 1 ? r * g.DY - dmin : r, so = g.SY == 1 ? s * g.DY - dmin : s;
+        pp.tapoff[t] = (ro * pp.PW + so) * kPosBytes;
+    }
+    pp.nchunks = cdiv(g.Cin, kCH);
+    pp.nstages = pp.nchunks * pp.NPH;
+    pp.nsteps = pp.nstages * pp.NT * 2;
+    pp.dPP = make_fastdiv((unsigned)pp.PP);
+    pp.dPHW = make_fastdiv((unsigned)pp.PHW);
+    pp.dPW = make_fastdiv((unsigned)pp.PW);
+    return pp;
+}
+
+PatchGather plan_patch_gather(const Geom& g, const PatchPlan& pp) {
+    PatchGather p;
+    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
+    p.ntiles = cdiv(g.Cout, p.bn);
+    p.ncls = g.OS * g.OS;
+    const int tiles = pp.mtiles * p.ntiles * p.ncls;
+    // fewer tiles than resident workgroups (256 CUs x 2): split the stages, keeping at least 4 per workgroup
+    int ks = 1;
+    if (tiles < 512) ks = std::max(1, std::min({512 / tiles, pp.nstages / 4, 32}));
+    p.stages_per_split = cdiv(pp.nstages, ks);
+    p.ksplit = cdiv(pp.nstages, p.stages_per_split);
+    p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
+    p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
+    return p;
+}
+
+size_t patch_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec) {
+    int ncls, K, N;
+    if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
+    int R, S, SY;
+    pack_taps(mode, kh, kw, R, S, SY);
+    const int Kin = K / (R * S);
+    const int nph = SY == 2 ? 4 : 1, nt = SY == 2 ? (R / 2) * (S / 2) : R * S;
+    const size_t nsteps = (size_t)cdiv(Kin, kCH) * nph * nt * 2;
+    return (size_t)ncls * nsteps * prec_planes(prec) * agan_round_up(N, 32) * 32;
+}
+
+int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, hipStream_t st) {
+    int ncls, K, N;
+    if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return AGAN_EINVAL;
+    int R, S, SY;
+    pack_taps(mode, kh, kw, R, S, SY);
+    // only the fields the pack kernel reads
+    PatchPlan pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.IS = SY;
+    pp.NPH = SY == 2 ? 4 : 1;
+    pp.NT = SY == 2 ? (R / 2) * (S / 2) : R * S;
+    const int Kin = K / (R * S);
+    pp.nchunks = cdiv(Kin, kCH);
+    pp.nstages = pp.nchunks * pp.NPH;
+    pp.nsteps = pp.nstages * pp.NT * 2;
+    const int Nld = agan_round_up(N, 32);
+    const size_t total = (size_t)ncls * pp.nsteps * Nld * 8;
+    const unsigned blocks = (unsigned)std::min<size_t>(cdivz(total, 256), 8192);
+    unsigned short* o = static_cast<unsigned short*>(wk);
+#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), dim3(blocks), dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp)
+    switch (prec) {
+        case AGAN_PREC_BF16: AGAN_PK(0, 1); break;
+        case AGAN_PREC_F16: AGAN_PK(1, 1); break;
+        case AGAN_PREC_BF16X3: AGAN_PK(0, 2); break;
+        case AGAN_PREC_BF16X6: AGAN_PK(0, 3); break;
+        default: return AGAN_EINVAL;
+    }
+#undef AGAN_PK
+    return check_launch("pack_weight/patch");
+}
+
+PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec) {
+    PatchWgrad p;
+    p.bj = prec_planes(prec) >= 3 ? 64 : 128;
+    if (g.Cout <= 64) p.bj = 64;
+    p.jtiles = cdiv(g.Cout, p.bj);
+    p.ncls = g.OS * g.OS;
+    const int wgs = p.jtiles * pp.nstages * p.ncls;
+    // one workgroup per CU is resident (LDS): split the pixel tiles until the grid covers the chip about twice
+    int ps = 1;
+    if (wgs < 512) ps = std::max(1, std::min(512 / wgs, pp.mtiles));
+    p.tiles_per_split = cdiv(pp.mtiles, ps);
+    p.psplit = cdiv(pp.mtiles, p.tiles_per_split);
+    p.Kp = pp.nstages * pp.NT * kCH;
+    p.slab = ((size_t)p.ncls * g.Cout * p.Kp + 3) / 4 * 4;
+    p.ws_bytes = p.slab * (p.psplit + (p.psplit > 1 ? 1 : 0)) * sizeof(float);      // partial slabs + the reduced one
+    return p;
+}
+
+void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
+                        hipStream_t st) {
+    switch (prec) {
+        case AGAN_PREC_BF16: if (p.bj == 128) launch_wg_nt<0, 1, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<0, 1, 64>(x, dy, part, g, pp, p, st); break;
+        case AGAN_PREC_F16: if (p.bj == 128) launch_wg_nt<1, 1, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<1, 1, 64>(x, dy, part, g, pp, p, st); break;
+        case AGAN_PREC_BF16X3: if (p.bj == 128) launch_wg_nt<0, 2, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<0, 2, 64>(x, dy, part, g, pp, p, st); break;
+        default: launch_wg_nt<0, 3, 64>(x, dy, part, g, pp, p, st); break;
+    }
+}
+
+void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,
+                               int accumulate, hipStream_t st) {
+    const size_t total = (size_t)cout * cin * kh * kw;
+    hipLaunchKernelGGL(unpack_patch_wgrad_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st, red, dw, cout, cin,
+                       kh, kw, up ? 1 : 0, pp.NPH, pp.NT, p.Kp, accumulate);
+}
+
+void launch_patch_gather(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp,
+                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st) {
+    switch (prec) {
+        case AGAN_PREC_BF16: launch_bn<0, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
+        case AGAN_PREC_F16: launch_bn<1, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
+        case AGAN_PREC_BF16X3: launch_bn<0, 2>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
+        default: launch_bn<0, 3>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
+    }
+}
+
+}  // namespace conv
+}  // namespace agan

@@ -90,9 +90,18 @@ class FlatAdam:
             p.grad = view
         return copies
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def join_and_rebind(self) -> None:
+        """Make the flat gradient buffer complete and current on this stream (what step() does first)."""
         HF.join_side_stream()          # weight gradients forked off the current stream (functional.set_wgrad_side_stream)
         self._rebind()
+
+    def named_gradients(self, module) -> Dict[str, Tensor]:
+        """{parameter name: view of its slice of the flat gradient buffer} for the trainable parameters of `module`"""
+        names = [k for k, p in module.named_parameters() if p.requires_grad]
+        return {k: self.grad[o:o + p.numel()].view(p.shape) for k, p, o in zip(names, self.params, self.offsets)}
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.join_and_rebind()
         self.step_count += 1
         if self.flat.is_cuda:
             HF.adam_step_(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_state, self.lr,

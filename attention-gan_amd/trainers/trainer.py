@@ -160,6 +160,9 @@ class GanTrainStep(ModelTrainer):
         # kernels that each fill the chip, so the extra concurrency only adds cache pressure.  Off by default.
         self.overlap_weight_gradients = False
         self._streams: List = []
+        # optional observer `f(tag, optimiser)` called right before each optimiser consumes its gradients (after the gradient
+        # exchange), tag in {"D0", "D1", "D2", "G"}: tests read the flat gradient buffers through it
+        self.on_gradients: Optional[Callable] = None
 
     def _d_streams(self, n: int, device) -> List:
         if len(self._streams) != n:
@@ -209,7 +212,11 @@ class GanTrainStep(ModelTrainer):
                 bk.arm()
                 loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
                 loss.backward()
-                opt.step(bk.finish())
+                scale = bk.finish()
+                if self.on_gradients is not None:
+                    opt.join_and_rebind()
+                    self.on_gradients(f"D{i}", opt)
+                opt.step(scale)
                 out[f"d_loss{i}"] = loss.detach()
         if streams is not None:
             for st in streams:
@@ -250,7 +257,11 @@ class GanTrainStep(ModelTrainer):
         total.backward()
         for d in self.Ds:
             d.requires_grad_(True)
-        self.g_opt.step(self.g_buckets.finish())
+        scale = self.g_buckets.finish()
+        if self.on_gradients is not None:
+            self.g_opt.join_and_rebind()
+            self.on_gradients("G", self.g_opt)
+        self.g_opt.step(scale)
         # loss histories stay device tensors: no .item() host sync inside the step (reference syncs at train.py:130,144-145)
         self.d_losses.append(out[f"d_loss{len(self.Ds) - 1}"])
         self.g_losses.append(out[f"g_loss{len(self.Ds) - 1}"])

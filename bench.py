@@ -30,7 +30,9 @@ if ROOT not in sys.path:
 GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (spec): f32 = v_mfma_f32_32x32x2_f32; bf16x3 is priced against the
 # bf16 peak although it issues three MFMAs per algorithmic product (its fraction can therefore not exceed 1/3)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0}
+# what the conv engine multiplies in, per --precision (fp32 storage and fp32 accumulate in every mode)
+DTYPE_NOTE = {"f32": "f32", "bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
 
 
 def algorithmic_conv_flops(kind, B, Cin, H, W, Cout, k):
@@ -159,16 +161,38 @@ def synthetic_batch(dev, batch, seed):
     return words, sent, lens, reals
 
 
-def cpu_baseline(batch):
-    """The CPU oracle (a port of the reference's step) timed on this box's host cores: one full step at the metric shapes."""
-    from oracle import attngan_oracle as O
+def usable_cores():
+    """host cores this process may really use: scheduler affinity, cut down to the cgroup CPU quota where one is set (a one-GPU
+    box exposes every core of the host but grants a 16-core share; more threads than that only oversubscribe)"""
     try:
-        avail = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))        # a one-GPU box shares 16 host cores; more threads only oversubscribe
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(batch, repeats=3):
+    """The CPU oracle (a port of the reference's step) timed on this box's host cores, as BASELINE.md section 4 prescribes: full
+    train steps at the metric shapes on all host cores available to the process, median of `repeats` after one warm-up step."""
+    from oracle import attngan_oracle as O
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: timing the CPU oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: timing the CPU oracle on {cores} threads (1 warm-up + {repeats} steps) ...", file=sys.stderr, flush=True)
     gp = O.make_generator_params(GF, EMB, Z, COND, seed=0)
     dps = [O.make_disc_params(DF, r, seed=0) for r in (64, 128, 256)]
     gopt, dopts = O.AdamState(gp), [O.AdamState(d) for d in dps]
@@ -177,21 +201,27 @@ def cpu_baseline(batch):
     words, sent = torch.randn(batch, EMB, T, generator=g), torch.randn(batch, EMB, generator=g)
     reals = [torch.rand(batch, 3, r, r, generator=g) * 2 - 1 for r in (64, 128, 256)]
     noise, eps = torch.randn(batch, Z, generator=g), torch.randn(batch, COND, generator=g)
-    t0 = time.perf_counter()
-    O.train_step(gp, dps, gopt, dopts, words, sent, [T] * batch, None, reals, noise, eps, lambda im: O.standin_encoder(im, ep))
-    dt = time.perf_counter() - t0
-    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 full train step, batch {batch}, same shapes as the GPU workload (no warm-up), {dt:.1f} s"}
+    times = []
+    for i in range(repeats + 1):
+        t0 = time.perf_counter()
+        O.train_step(gp, dps, gopt, dopts, words, sent, [T] * batch, None, reals, noise, eps, lambda im: O.standin_encoder(im, ep))
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(batch / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"full train steps, batch {batch}, same shapes as the GPU workload: median of {repeats} after 1 warm-up "
+                      f"({', '.join(f'{t:.1f}' for t in times)} s)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps (default: a >= 3 s timed region at the metric config)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
-                    help="MFMA mode of the conv engine: f32 = exact fp32 products (parity mode, default); bf16x3 = 3-term bf16 split")
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "bf16x3", "bf16", "f16"], default="f32",
+                    help="MFMA mode of the conv engine: f32 = exact fp32 products (v_mfma_f32_32x32x2_f32); bf16x6 = three bf16 planes, "
+                         "6 MFMAs per product (fp32-grade); bf16x3 = two planes, 3 MFMAs; bf16 / f16 = operands rounded to 16 bits "
+                         "(BASELINE configs[1] / configs[4] arithmetic)")
     ap.add_argument("--image-encoder", choices=["standin", "inception"], default="standin",
                     help="frozen DAMSM image encoder plug-in: 'standin' = contract-only stub (SURVEY §8d prices the hot path without "
                          "the third-party trunk); 'inception' = Inception-v3-shaped trunk on stock MIOpen convs, random weights")
@@ -227,7 +257,7 @@ def main():
 
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     LIB = importlib.import_module("attention-gan_amd.backend.lib")
-    HF.set_precision(LIB.PREC_F32 if args.precision == "f32" else LIB.PREC_BF16X3)
+    HF.set_precision(LIB.PRECISIONS[args.precision])
     step = build(dev, args.batch, HF, args.image_encoder)
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
     timer = ConvTimer(importlib.import_module("attention-gan_amd.backend.lib"), args.precision)
@@ -332,7 +362,7 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
             "config": {"workload": "full 3-stage AttnGAN 64->128->256 train step: G + 3xD updates + word attention + DAMSM words/sentence "
                                    "loss + KL + 4x fused Adam (BASELINE.json configs[2])",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "gf_dim": GF, "df_dim": DF, "emb_dim": EMB,

@@ -36,10 +36,17 @@ enum {
 
 /* arithmetic mode of the MFMA contractions (fp32 storage everywhere, fp32 accumulate always) */
 enum {
-    AGAN_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity mode)             */
-    AGAN_PREC_BF16 = 1,  /* (reserved) operands rounded to bf16, single MFMA pass: not built -- fails the 1e-3 parity bar */
-    AGAN_PREC_BF16X3 = 2 /* bf16 hi/lo split, 3 MFMAs per product: ~fp32 accuracy at bf16 MFMA rate */
+    AGAN_PREC_F32 = 0,    /* v_mfma_f32_32x32x2_f32: exact fp32 products                                              */
+    AGAN_PREC_BF16 = 1,   /* operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (BASELINE configs[1])                 */
+    AGAN_PREC_BF16X3 = 2, /* bf16 hi/lo split (16 mantissa bits), 3 MFMAs per product                                 */
+    AGAN_PREC_F16 = 3,    /* operands rounded to fp16, v_mfma_f32_32x32x16_f16 (BASELINE configs[4])                  */
+    AGAN_PREC_BF16X6 = 4  /* bf16 hi/mid/lo split (24 mantissa bits), 6 MFMAs per product: fp32-grade products at 2.67x
+                             the fp32-MFMA rate                                                                       */
 };
+/* The 16-bit modes run on the patch-resident kernels (csrc/conv_patch.hip), which take 3x3 / 2x2-per-class stride-1 and 4x4
+ * stride-2 geometries with more than 4 output channels and images of at least 4x4; any other call (linear layers, the RGB
+ * heads) runs in AGAN_PREC_F32 whatever mode is asked for.  agan_conv_effective_prec says which one a geometry gets -- pack the
+ * weights for THAT precision (declared below, after agan_conv_geom). */
 
 int agan_version(void);
 const char* agan_last_error(void);
@@ -77,8 +84,9 @@ enum {
     AGAN_PACK_UP_DGRAD = 4   /* its dgrad folded into one 4x4 stride-2 conv over dY                                         */
 };
 
-/* Packed size in BYTES for a precision mode: AGAN_PREC_F32 -> fp32 [cls][K][Nld];  AGAN_PREC_BF16X3 -> bf16 hi and lo planes
- * [cls][2][Nld][Kp] (Kp = K rounded up to 32, k fastest).  0 = mode/kernel-size/precision combination not supported. */
+/* Packed size in BYTES for a precision mode: AGAN_PREC_F32 -> fp32 [cls][K][Nld];  the 16-bit modes -> [cls][k-step][plane][Nld][16]
+ * (k-step = 16 channels of one tap, ordered chunk of 32 channels > input phase > tap > half; planes = 1 / 2 / 3 for
+ * BF16, F16 / BF16X3 / BF16X6): the 32 x 16 operand block of a wave is 1 KB contiguous.  0 = combination not supported. */
 size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
 /* w: OIHW [cout][cin][kh][kw] -> wk (see modes).  Replaces nothing in the reference: layout prep for the kernels below. */
 int agan_pack_weight(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, void* stream);
@@ -103,6 +111,7 @@ int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, in
 size_t agan_conv_ktable_elems(const agan_conv_geom* g);
 int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
 
+int agan_conv_effective_prec(const agan_conv_geom* g, int prec);
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
 /* lrelu_mask (optional, data-gradient launches): a tensor of the OUTPUT's shape; out is multiplied by LeakyReLU'(mask) = 1 where
  * mask > 0, else 0.2 -- the backward of the LeakyReLU that produced this conv's forward input (the mask is that input), folded

@@ -53,3 +53,58 @@ def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         return sock.getsockname()[1]
+
+
+class LeakyMaskRecorder:
+    """Records, in call order, the branch every LeakyReLU of the HIP path took (sign of its output), per discriminator call.
+
+    `with LeakyMaskRecorder(discriminators) as rec:` ... run the HIP step ...; `rec.calls` is then a list of
+    (discriminator index, batch size, [bool mask per LeakyReLU layer, CPU]) in the order the discriminators were called.
+    Feed them to the oracle through oracle.LEAKY_MASKS (see oracle.leaky) so that both sides differentiate the same branch."""
+
+    def __init__(self, discriminators):
+        import importlib
+        self.LAY = importlib.import_module("attention-gan_amd.utilities.layers")
+        self.L = importlib.import_module("attention-gan_amd.backend.lib")
+        self.Ds = list(discriminators)
+        self.calls = []
+        self._cur = None
+
+    def __enter__(self):
+        LAY, L = self.LAY, self.L
+        self._conv, self._fused = LAY.HipConv2d.forward, LAY._BNState.fused
+        self._fwd = [type(d).forward for d in self.Ds]
+        rec = self
+
+        def conv_fwd(mod, x, act=L.ACT_NONE, *a, **k):
+            y = rec._conv(mod, x, act, *a, **k)
+            if act == L.ACT_LRELU and rec._cur is not None:
+                rec._cur.append((y.detach() >= 0).cpu())
+            return y
+
+        def bn_fused(mod, x, act, residual=None):
+            y = rec._fused(mod, x, act, residual)
+            if act == L.ACT_LRELU and rec._cur is not None:
+                rec._cur.append((y.detach() >= 0).cpu())
+            return y
+
+        LAY.HipConv2d.forward, LAY._BNState.fused = conv_fwd, bn_fused
+        self._patched = []
+        for i, d in enumerate(self.Ds):
+            orig = d.forward
+
+            def fwd(X, _orig=orig, _i=i):
+                rec._cur = []
+                out = _orig(X)
+                rec.calls.append((_i, int(X.shape[0]), rec._cur))
+                rec._cur = None
+                return out
+            d.forward = fwd
+            self._patched.append(d)
+        return self
+
+    def __exit__(self, *exc):
+        self.LAY.HipConv2d.forward, self.LAY._BNState.fused = self._conv, self._fused
+        for d in self._patched:
+            del d.forward
+        return False

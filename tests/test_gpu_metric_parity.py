@@ -4,12 +4,19 @@ One train step (train.py:109-151) runs on the HIP path and on `oracle.train_step
 seeded inputs (random caption lengths 2..10, like the reference's batches).  Compared per tensor:
 
   * the three fake images, the two word-attention maps, mu / logvar and the ten losses: 1e-3 of the tensor's maximum (RTOL);
-  * every gradient the four optimisers consume (97 generator tensors, 29 + 37 + 45 discriminator tensors): 1e-3 against the
-    fp32 oracle where the tensor is well-conditioned.  Where it is not -- fresh discriminators on uniform-noise images: the
-    per-channel sums BatchNorm's backward subtracts cancel to ~1e-2 of their terms, so ANY two fp32 summation orders differ by
-    more than 1e-3 there -- the judge of record is the oracle run once in fp64: the HIP result must be no further from it than
-    twice the distance of the fp32 oracle itself (err(HIP, f64) <= 2 x err(oracle f32, f64)), i.e. the HIP path is as good an
-    fp32 evaluation of the reference's step as the reference's own CPU kernels are.
+  * every gradient the four optimisers consume (97 generator tensors, 12 + 18 + 24 discriminator tensors): 1e-3 against the
+    fp32 oracle where the tensor is well-conditioned.  Where it is not -- at initialisation a discriminator cannot tell real
+    from fake, so its weight gradient is the small difference of two large sums (the real and the fake pass) and ANY two fp32
+    summation orders differ by more than 1e-3 -- the judge of record is the oracle run once in fp64: the HIP result must be no
+    further from it than twice the distance of the fp32 oracle itself (err(HIP, f64) <= 2 x err(oracle f32, f64)), i.e. the
+    HIP path is as good an fp32 evaluation of the reference's step as the reference's own CPU kernels are.
+
+Kink synchronisation.  LeakyReLU(0.2) makes a discriminator's gradient a discontinuous function of its inputs: a
+pre-activation within a rounding error of zero (about one element per layer and pass at this size) takes slope 1 in one fp32
+evaluation and 0.2 in another, and that one element moves every upstream gradient tensor by ~1e-2 of its maximum -- in the
+fp32 oracle against the fp64 oracle just as in HIP against either (measured).  The test therefore records
+the branch each LeakyReLU of the HIP step took and lets the oracle differentiate the SAME branch (oracle.LEAKY_MASKS), so what
+is compared at 1e-3 is the arithmetic of the kernels, not the coin flips of a measure-zero set.
 
 The observed per-tensor errors are printed (pytest -s shows them; on failure they are in the assertion message).
 """
@@ -20,7 +27,9 @@ import sys
 import pytest
 import torch
 
-from helpers import RTOL, rel_err
+from collections import deque
+
+from helpers import RTOL, LeakyMaskRecorder, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -31,16 +40,41 @@ LOSSES = ("d_loss0", "d_loss1", "d_loss2", "g_loss0", "g_loss1", "g_loss2", "w_l
 
 
 def _cast(p, dt):
-    return {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in p.items()}
+    # always a COPY: the oracle's step updates its parameters and BatchNorm statistics in place
+    return {k: (v.to(dt, copy=True) if v.is_floating_point() else v.clone()) for k, v in p.items()}
 
 
-def _oracle_step(gp, dps, ep, data, dt):
+def _mask_queue(calls, n_disc):
+    """HIP call order: paired [real; fake] pass of D0, D1, D2 (D updates), then D0, D1, D2 on the fakes (G update).
+    Oracle call order (train_step): per D the real pass then the fake pass; then the three G-update passes."""
+    assert len(calls) == 2 * n_disc and [c[0] for c in calls] == list(range(n_disc)) * 2, [c[:2] for c in calls]
+    q = deque()
+    for i, nb, masks in calls[:n_disc]:
+        half = nb // 2
+        q.extend(m[:half] for m in masks)
+        q.extend(m[half:] for m in masks)
+    for i, nb, masks in calls[n_disc:]:
+        q.extend(masks)
+    return q
+
+
+def _oracle_step(gp, dps, ep, data, dt, calls):
     gp, dps, ep = _cast(gp, dt), [_cast(d, dt) for d in dps], _cast(ep, dt)
     f = lambda t: t.to(dt)
     cap = {}
+    O.LEAKY_MASKS = _mask_queue(calls, len(dps))
+    try:
+        out = _run_oracle(gp, dps, ep, data, f, cap)
+        assert not O.LEAKY_MASKS, f"{len(O.LEAKY_MASKS)} LeakyReLU masks left over"
+    finally:
+        O.LEAKY_MASKS = None
+    return out, cap
+
+
+def _run_oracle(gp, dps, ep, data, f, cap):
     out = O.train_step(gp, dps, O.AdamState(gp), [O.AdamState(d) for d in dps], f(data["words"]), f(data["sent"]), data["lens"], None,
                        [f(r) for r in data["reals"]], f(data["noise"]), f(data["eps"]), lambda im: O.standin_encoder(im, ep), capture=cap)
-    return out, cap
+    return out
 
 
 def test_metric_config_step_vs_oracle():
@@ -60,21 +94,23 @@ def test_metric_config_step_vs_oracle():
                 noise=torch.randn(B, bench.Z, generator=g), eps=torch.randn(B, bench.COND, generator=g))
     # ---- HIP path ----
     to = lambda t: t.to(DEV)
-    out = step.step(to(data["words"]), to(data["sent"]), lens, None, [to(r) for r in data["reals"]], to(data["noise"]), to(data["eps"]))
-    torch.cuda.synchronize()
-    hip = {f"loss/{k}": out[k].cpu() for k in LOSSES}
+    hip = {}
+
+    def grab(tag, opt):          # the gradients each optimiser is about to consume
+        mod = step.G if tag == "G" else step.Ds[int(tag[1])]
+        for k, v in opt.named_gradients(mod).items():
+            hip[f"g{tag}/{k}"] = v.detach().cpu().clone()
+    step.on_gradients = grab
+    with LeakyMaskRecorder(step.Ds) as rec:
+        out = step.step(to(data["words"]), to(data["sent"]), lens, None, [to(r) for r in data["reals"]], to(data["noise"]), to(data["eps"]))
+        torch.cuda.synchronize()
+    calls = rec.calls
+    hip.update({f"loss/{k}": out[k].cpu() for k in LOSSES})
     for i in range(3):
         hip[f"fake{i}"] = out["fake_imgs"][i].cpu()
     for i in range(2):
         hip[f"attn{i}"] = out["attn_maps"][i].cpu()
     hip["mu"], hip["logvar"] = out["mu"].cpu(), out["logvar"].cpu()
-    for k, p in step.G.named_parameters():
-        assert p.grad is not None, f"G.{k} received no gradient"
-        hip[f"gG/{k}"] = p.grad.detach().cpu().clone()
-    for i, d in enumerate(step.Ds):
-        for k, p in d.named_parameters():
-            assert p.grad is not None, f"D{i}.{k} received no gradient"
-            hip[f"gD{i}/{k}"] = p.grad.detach().cpu().clone()
     del out, step
     torch.cuda.empty_cache()
 
@@ -93,8 +129,8 @@ def test_metric_config_step_vs_oracle():
                 r[f"gD{i}/{k}"] = v
         return r
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
-    o32 = flatten(*_oracle_step(gp, dps, ep, data, torch.float32))
-    o64 = flatten(*_oracle_step(gp, dps, ep, data, torch.float64))
+    o32 = flatten(*_oracle_step(gp, dps, ep, data, torch.float32, calls))
+    o64 = flatten(*_oracle_step(gp, dps, ep, data, torch.float64, calls))
 
     assert set(hip) == set(o32) == set(o64), sorted(set(hip) ^ set(o32))
     rows, bad = [], []

@@ -323,12 +323,13 @@ def test_metric_config_step_properties():
 
 def test_paired_discriminator_pass_at_metric_size():
     """Disc256 (df 64) on 24 + 24 images of 256x256: the one-pass [real; fake] update and the reference's two passes
-    (disc_loss.py:55-61), both against the CPU oracle.  Loss and BatchNorm running statistics agree to rounding.  Gradients:
-    within RTOL of the fp32 oracle where the tensor is well-conditioned; on this input (uniform-noise images through a freshly
-    initialised D) the per-channel sums BatchNorm's backward subtracts cancel to ~1e-2 of their terms upstream of the last
-    stride-2 stage, so any two fp32 summation orders differ by more than that -- there the fp64 oracle decides: each HIP form
-    must be no further from it than twice the fp32 oracle's own distance (same rule as test_gpu_metric_parity.py)."""
-    from helpers import rel_err
+    (disc_loss.py:55-61), against each other and against the CPU oracle.  The two HIP forms take identical LeakyReLU branches
+    (same per-group statistics, same arithmetic), so they are compared directly; the oracle differentiates the branches the HIP
+    pass took (oracle.LEAKY_MASKS -- see tests/test_gpu_metric_parity.py for why) and every gradient must be within RTOL of
+    it, or -- where the real and the fake pass cancel to a small difference -- no further from the fp64 oracle than twice the
+    fp32 oracle's own distance."""
+    from collections import deque
+    from helpers import LeakyMaskRecorder, rel_err
     DL = importlib.import_module("attention-gan_amd.losses.disc_loss").NonSaturatingDiscLoss
     torch.manual_seed(8)
     da, db = DISC.Disc256(64).to(DEV), DISC.Disc256(64).to(DEV)
@@ -339,20 +340,29 @@ def test_paired_discriminator_pass_at_metric_size():
     fake = torch.rand(24, 3, 256, 256, generator=gen) * 2 - 1
     one, two = DL(), DL()
     two.batch_pairs = False
-    la, lb = one.get_loss(da, fake.to(DEV), real.to(DEV)), two.get_loss(db, fake.to(DEV), real.to(DEV))
+    with LeakyMaskRecorder([da]) as rec:
+        la = one.get_loss(da, fake.to(DEV), real.to(DEV))
+    lb = two.get_loss(db, fake.to(DEV), real.to(DEV))
     la.backward()
     lb.backward()
     assert_close(la, lb, 1e-6, "loss")
     for (k, ba), (_, bb) in zip(da.named_buffers(), db.named_buffers()):
         if not k.endswith("num_batches_tracked"):
             assert_close(ba, bb, 1e-6, f"buffer {k}")
+    (_, nb, masks), = rec.calls
+    assert nb == 48
 
     def oracle(dt):
-        p = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in p0.items()}
+        p = {k: (v.to(dt, copy=True) if v.is_floating_point() else v.clone()) for k, v in p0.items()}
         keys = O.trainable_keys(p)
         for k in keys:
             p[k].requires_grad_(True)
-        loss = O.ns_disc_loss(O.disc_forward(p, real.to(dt), 256), O.disc_forward(p, fake.to(dt), 256))
+        O.LEAKY_MASKS = deque([m[:24] for m in masks] + [m[24:] for m in masks])
+        try:
+            loss = O.ns_disc_loss(O.disc_forward(p, real.to(dt), 256), O.disc_forward(p, fake.to(dt), 256))
+            assert not O.LEAKY_MASKS
+        finally:
+            O.LEAKY_MASKS = None
         return loss.detach(), dict(zip(keys, torch.autograd.grad(loss, [p[k] for k in keys]))), p
     l32, g32, p32 = oracle(torch.float32)
     l64, g64, _ = oracle(torch.float64)

@@ -26,29 +26,38 @@ DEV = "cuda"
 
 
 class _Tol:
-    """AGAN_PREC_F32 multiplies exactly in fp32: agreement is ~1e-6 and held to 2e-4.  AGAN_PREC_BF16X3 (3-term bf16 split,
-    ~2^-16 per product) is held to the north_star bar itself, 1e-3 relative."""
+    """Per-mode bound on max|got - want| / max|want| for ONE conv-engine layer or fused block:
+    f32      exact fp32 products (v_mfma_f32_32x32x2_f32): agreement ~1e-6, held to 2e-4;
+    bf16x6   three bf16 planes = 24 mantissa bits, six MFMAs per product: fp32-grade, held to the same 2e-4;
+    bf16x3   two bf16 planes (~2^-16 per product): north_star's 1e-3;
+    f16      operands rounded to fp16 (2^-11): 3e-3;       bf16  operands rounded to bf16 (2^-8): 2e-2
+    (rounded operands give a relative error of 2^-p / sqrt(K)-ish per output against the tensor's maximum; the bounds are ~4x
+    what the conv cases below measure)."""
     tight = 2e-4
 
 
 TOL = _Tol()
+MODE_TOL = {"f32": 2e-4, "bf16x6": 2e-4, "bf16x3": RTOL, "f16": 3e-3, "bf16": 2e-2}
+
+# Which tests run under which arithmetic mode.  f32 and bf16x6 (both fp32-grade) run EVERYTHING.  The rounded / 16-bit-mantissa
+# modes run the conv engine, the fused blocks and the metric-batch comparison: the whole-network golden fixtures use batch
+# 2-4, where train-mode BatchNorm over a handful of samples amplifies any perturbation ~10^3x (the exact-fp32 mode itself
+# lands at 1e-4..1e-3 there), so products that are not fp32-grade cannot meet 1e-3 on them.
+LOWP_TESTS = ("test_conv_engine_vs_oracle", "test_conv_metric_shape_properties", "test_blocks_vs_golden",
+              "test_lowp_modes_vs_f32_at_metric_batch")
+ROUNDED_TESTS = ("test_conv_engine_vs_oracle", "test_conv_metric_shape_properties", "test_lowp_modes_vs_f32_at_metric_batch")
 
 
-# Tests that also run under AGAN_PREC_BF16X3.  The whole-network golden fixtures use batch 2-4, where train-mode BatchNorm
-# over a handful of samples amplifies any perturbation ~10^3x (the exact-fp32 mode itself lands at 1e-4..1e-3 there), so the
-# 2^-16 products of the split mode cannot meet 1e-3 on them; it is held to 1e-3 on the conv engine, the fused blocks and at
-# the metric batch size (test_bf16x3_vs_f32_at_metric_batch).  bench.py's default and the parity claim are the f32 mode.
-BF16X3_TESTS = ("test_conv_engine_vs_oracle", "test_conv_metric_shape_properties", "test_blocks_vs_golden",
-                "test_bf16x3_vs_f32_at_metric_batch")
-
-
-@pytest.fixture(params=["f32", "bf16x3"], autouse=True)
+@pytest.fixture(params=["f32", "bf16x6", "bf16x3", "f16", "bf16"], autouse=True)
 def precision_mode(request):
-    if request.param == "bf16x3" and request.node.originalname not in BF16X3_TESTS:
-        pytest.skip("exact-fp32 mode only (see BF16X3_TESTS)")
+    name = request.node.originalname
+    if request.param == "bf16x3" and name not in LOWP_TESTS:
+        pytest.skip("fp32-grade modes only (see LOWP_TESTS)")
+    if request.param in ("f16", "bf16") and name not in ROUNDED_TESTS:
+        pytest.skip("fp32-grade modes only (see ROUNDED_TESTS)")
     L = importlib.import_module("attention-gan_amd.backend.lib")
-    HF.set_precision(L.PREC_F32 if request.param == "f32" else L.PREC_BF16X3)
-    TOL.tight = 2e-4 if request.param == "f32" else RTOL
+    HF.set_precision(L.PRECISIONS[request.param])
+    TOL.tight = MODE_TOL[request.param]
     yield request.param
     HF.set_precision(L.PREC_F32)
     TOL.tight = 2e-4
@@ -140,44 +149,43 @@ def test_conv_metric_shape_properties():
     x2 = torch.randn(B, Cin, H, H, generator=g).to(DEV)
     y1, y2 = HF.conv2d(x1, w, None, "same"), HF.conv2d(x2, w, None, "same")
     y12 = HF.conv2d(x1 + 2 * x2, w, None, "same")
-    assert_close(y12, y1 + 2 * y2, 1e-5 if TOL.tight < 1e-3 else 1e-4, "linearity")
+    assert_close(y12, y1 + 2 * y2, max(1e-5, TOL.tight / 2), "linearity")
     ones = torch.ones(1, Cin, H, H, device=DEV)
     yo = HF.conv2d(ones, w, None, "same")
-    lin = 1e-5 if TOL.tight < 1e-3 else 1e-4
+    lin = max(1e-5, TOL.tight / 2)
     assert_close(yo[0, :, 5, 5], w.sum(dim=(1, 2, 3)), lin, "interior = sum of taps")
     assert_close(yo[0, :, 0, 0], w[:, :, 1:, 1:].sum(dim=(1, 2, 3)), lin, "corner = 2x2 taps")
 
 
-def test_bf16x3_vs_f32_at_metric_batch(precision_mode):
-    """Disc256 at the metric batch (B=24, df=16 to keep it quick): forward, input gradient and weight gradients of the bf16x3
-    mode against the exact-fp32 mode of the same HIP path -- the well-conditioned regime the split mode is meant for."""
-    if precision_mode != "bf16x3":
-        pytest.skip("comparison is run once, from the bf16x3 instance")
+def test_lowp_modes_vs_f32_at_metric_batch(precision_mode):
+    """Disc256 at the metric batch (B=24, df=16 to keep it quick): forward, input gradient and weight gradients of every other
+    arithmetic mode against the exact-fp32 mode of the same HIP path.  The forward is held to the mode's per-layer bound x 5
+    (9 conv layers); gradients in relative L2 -- LeakyReLU kinks turn a perturbation of a near-zero pre-activation into an
+    isolated O(1) pointwise deviation, so max-norm is the wrong yardstick for anything but an fp32-grade mode."""
+    if precision_mode == "f32":
+        pytest.skip("the other modes are compared against this one")
     L = importlib.import_module("attention-gan_amd.backend.lib")
     torch.manual_seed(11)
     D = DISC.Disc256(16).to(DEV).train()
     x = (torch.rand(24, 3, 256, 256, device=DEV) * 2 - 1)
     outs = {}
-    for mode in (L.PREC_F32, L.PREC_BF16X3):
+    for mode in (L.PREC_F32, L.PRECISIONS[precision_mode]):
         HF.set_precision(mode)
         D.zero_grad()
         xi = x.clone().requires_grad_(True)
         y = D(xi)
         (y * probe(y.shape, 0.2).to(DEV)).sum().backward()
         outs[mode] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters()})
-    HF.set_precision(L.PREC_BF16X3)
-    ref, got = outs[L.PREC_F32], outs[L.PREC_BF16X3]
+    ref, got = outs[L.PREC_F32], outs[L.PRECISIONS[precision_mode]]
     def l2(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
-    print("bf16x3 vs f32 @B=24: y max-rel %.2e | dx L2 %.2e | worst weight-grad L2 %.2e" % (
-        float((got[0] - ref[0]).abs().max() / ref[0].abs().max()), l2(got[1], ref[1]), max(l2(got[2][k], ref[2][k]) for k in ref[2])))
-    assert_close(got[0], ref[0], RTOL, "D256(x) B=24")
-    # gradients: LeakyReLU kinks / BatchNorm mean-subtraction turn the 3e-5 per-layer noise of the split products into isolated
-    # large pointwise deviations (max-norm 1e-2..1e-1) while the gradient as a whole moves by ~2 % (measured 1.7 % on dx): bounded in L2.
-    # This is why bf16x3 is an opt-in throughput mode and NOT the parity mode.
-    assert l2(got[1], ref[1]) < 5e-2, "dx B=24"
-    for k in ref[2]:
-        assert l2(got[2][k], ref[2][k]) < 5e-2, f"grad {k} B=24"
+    worst = max(l2(got[2][k], ref[2][k]) for k in ref[2])
+    print("%s vs f32 @B=24: y max-rel %.2e | dx L2 %.2e | worst weight-grad L2 %.2e" % (
+        precision_mode, float((got[0] - ref[0]).abs().max() / ref[0].abs().max()), l2(got[1], ref[1]), worst))
+    assert_close(got[0], ref[0], 5 * MODE_TOL[precision_mode], "D256(x) B=24")
+    bound = {"bf16x6": 2e-3, "bf16x3": 5e-2, "f16": 1e-1, "bf16": 5e-1}[precision_mode]
+    assert l2(got[1], ref[1]) < bound, "dx B=24"
+    assert worst < bound, "weight gradients B=24"
 
 
 # ------------------------------------------------------------------------------------------------ blocks vs golden

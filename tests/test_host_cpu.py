@@ -43,8 +43,21 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.agan_packed_weight_bytes(L.PACK_UP_FWD, 8, 8, 4, 4, L.PREC_F32) == 0          # folded upsample conv is 3x3 only
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_F32) == 32 * 9 * 32 * 4   # Nld = round_up(3, 32)
     assert lib.agan_packed_weight_bytes(L.PACK_UP_FWD, 64, 64, 3, 3, L.PREC_F32) == 4 * 64 * 4 * 64 * 4
-    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16X3) == 2 * 32 * 288 * 2  # hi+lo planes [Nld][Kp]
-    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16) == 0               # single-pass bf16 is not built
+    # 16-bit modes: [k-step = 16 channels of a tap][plane][Nld][16] x 2 bytes; 32 channels x 9 taps = 18 k-steps
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16X3) == 18 * 2 * 32 * 32
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16) == 18 * 1 * 32 * 32
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_F16) == 18 * 1 * 32 * 32
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 40, 4, 4, L.PREC_BF16X6) == 2 * 4 * 4 * 2 * 3 * 32 * 32   # 2 chunks x 4 phases x 4 taps
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, 9) == 0                           # unknown mode
+    # effective precision: the patch kernels take 3x3 / 2x2-per-class / 4x4-s2 geometries with > 4 output channels
+    g3 = L.ConvGeom()
+    g3.B, g3.Cin, g3.IH, g3.IW, g3.Cout, g3.OH, g3.OW, g3.R, g3.S, g3.OS, g3.SY, g3.DY = 2, 16, 8, 8, 24, 8, 8, 3, 3, 1, 1, 1
+    g3.OY[0] = g3.OY[1] = -1
+    assert lib.agan_conv_effective_prec(g3, L.PREC_BF16) == L.PREC_BF16 and lib.agan_conv_effective_prec(g3, L.PREC_F32) == L.PREC_F32
+    g3.Cout = 3
+    assert lib.agan_conv_effective_prec(g3, L.PREC_BF16X6) == L.PREC_F32                         # RGB head: vector-ALU kernels
+    g3.Cout, g3.R, g3.S, g3.OY[0], g3.OY[1] = 24, 1, 1, 0, 0
+    assert lib.agan_conv_effective_prec(g3, L.PREC_F16) == L.PREC_F32                            # 1x1 / linear: fp32 MFMA
     rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, 0, None, None, 0, None)
     assert rc == -1 and b"conv" in lib.agan_last_error()
 
