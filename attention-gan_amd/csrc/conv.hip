@@ -941,8 +941,14 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
-    // geometries the patch kernels do not take run on the fp32 MFMA kernels (the operands are fp32 activations either way)
+    // geometries the patch kernels do not take run on the fp32 MFMA kernels (the operands are fp32 activations either way).
+    // AGAN_PREC_BF16X6 is fp32-grade by definition, so its weight gradients may use whichever fp32-grade kernel is faster:
+    // today that is the fp32 MFMA kernel (measured at the metric config: 6.5 vs 10 ms per step; build with
+    // -DAGAN_BF16X6_PATCH_WGRAD=1 to run the six-product patch kernel instead).
     if (prec != AGAN_PREC_F32 && !patch_supported(make_geom(gg))) prec = AGAN_PREC_F32;
+#ifndef AGAN_BF16X6_PATCH_WGRAD
+    if (prec == AGAN_PREC_BF16X6) prec = AGAN_PREC_F32;
+#endif
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
     const bool up = pack_mode == AGAN_PACK_UP_FWD;

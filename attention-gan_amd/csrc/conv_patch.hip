@@ -112,8 +112,11 @@ __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&w)[NPL], const u32x4 
 // ================================================================================================
 // forward / data-gradient kernel
 // ================================================================================================
+#ifndef AGAN_PATCH_OCC1
+#define AGAN_PATCH_OCC1 3
+#endif
 template <int ET, int NPL, int BN, int NT>
-__global__ __launch_bounds__(256) void conv_patch_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wk,
+__global__ __launch_bounds__(256, NPL == 1 ? AGAN_PATCH_OCC1 : 2) void conv_patch_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wk,
                                                          const float* __restrict__ bias, float* __restrict__ out, const Geom g,
                                                          const PatchPlan pp, const int ksplit, const int stages_per_split,
                                                          const size_t slab, const int act, const float* __restrict__ lrelu_mask) {
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const float* __restrict
         it_lds[i] = (unsigned)(p * kPosBytes + oct * 16);
     }
     float sreg[kItems][8];
+    const bool cin8 = (g.Cin & 7) == 0;
 
     auto load_patch = [&](int stage) {
         const int chunk = stage / pp.NPH, ph = stage - chunk * pp.NPH;
@@ -175,10 +179,15 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const float* __restrict
         for (int i = 0; i < kItems; ++i) {
             const int iy = it_iy[i] + by, ix = it_ix[i] + bx;
             const bool ok = (it_cb[i] >= 0) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-            const unsigned voff = ok ? (unsigned)(it_cb[i] + c0 * ihw + iy * g.IW + ix) * 4u : kOOB;
             const int nrem = g.Cin - c0 - it_oct[i] * 8;                    // channels of this octet that exist
+            const unsigned voff = (ok & (nrem > 0)) ? (unsigned)(it_cb[i] + c0 * ihw + iy * g.IW + ix) * 4u : kOOB;
+            if (cin8) {                                                     // whole octets only: no per-channel test
 #pragma unroll
-            for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, voff, (unsigned)(c * ihw) * 4u);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+            }
         }
     };
     auto store_patch = [&]() {
@@ -267,22 +276,30 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const float* __restrict
     const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);
     const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    // per-lane part of the address in the vector offset (pixel, and the 4*lh channel rows of this half-wave); the channel of
+    // accumulator register r is wave-uniform and goes into the instruction's scalar offset: no per-store address arithmetic
+    const int nw = n0 + wn * 32;
+    const bool nfull = nw + 32 <= g.Cout;                    // whole 32-channel block inside the tensor (the common case)
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : dst, (size_t)g.Cout * sizeof(float));
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int l = (wm * TM + t) * 32 + l31;
         const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
         const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
         const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
-        const unsigned pixoff = (unsigned)(b * g.Cout) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
+        const unsigned pixoff = (unsigned)(b * g.Cout + nw + 4 * lh) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
+        const unsigned voff = pvalid ? pixoff * 4u : kOOB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            constexpr int dummy = 0; (void)dummy;
+            const int nr = (r & 3) + 8 * (r >> 2);           // channel row of register r inside the block (+ 4*lh, per lane)
             float v = acc[t][r];
-            if (add_bias) v += bias[min(n, g.Cout - 1)];
+            if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
             if (lrelu) v = v > 0.f ? v : 0.2f * v;
-            const unsigned off = (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB;
-            if (masked) v = buf_load(rmask, off) > 0.f ? v : 0.2f * v;
-            buf_store(rout, off, v);
+            const unsigned so = (unsigned)nr * (unsigned)ohw * 4u;
+            const unsigned vo = (nfull || (nw + nr + 4 * lh < g.Cout)) ? voff : kOOB;
+            if (masked) v = buf_load_s(rmask, vo, so) > 0.f ? v : 0.2f * v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, so, 0);
         }
     }
 }
