@@ -99,20 +99,23 @@ __device__ __host__ inline void up_dgrad_taps(int t, int& lo, int& hi) {
 
 
 // Value of packed-weight element (class cls, reduction index k, output column n) for each agan_pack_weight mode (0 = padding).
-__device__ inline float packed_weight_value(const float* __restrict__ w, int mode, int cls, int k, int n, int cout, int cin, int kh, int kw) {
+// W4(co, ci, a, b) returns element [co][ci][a][b] of the OIHW tensor (the caller's accessor: global memory or an LDS tile).
+template <class W4>
+__device__ inline float packed_weight_value_f(W4 w4, int mode, int cls, int k, int n, int cout, int cin, int kh, int kw) {
     float v = 0.f;
     if (mode == AGAN_PACK_FWD) {
-        const int K = cin * kh * kw;
-        if (n < cout) v = w[(size_t)n * K + k];
+        // k = (ci, r, s), n = co
+        const int khw = kh * kw, ci = k / khw, rs = k - ci * khw, r = rs / kw, s = rs - r * kw;
+        if (n < cout) v = w4(n, ci, r, s);
     } else if (mode == AGAN_PACK_DGRAD_S1) {
         // k = (co, r, s), n = ci
         const int khw = kh * kw, co = k / khw, rs = k - co * khw, r = rs / kw, s = rs - r * kw;
-        if (n < cin) v = w[(((size_t)co * cin + n) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)];
+        if (n < cin) v = w4(co, n, kh - 1 - r, kw - 1 - s);
     } else if (mode == AGAN_PACK_DGRAD_4x4S2) {
         // cls = (py,px); k = (co, r, s) with r,s in {0,1}; n = ci; tap kh = ((py+1)&1) + 2r
         const int py = cls >> 1, px = cls & 1, co = k >> 2, r = (k >> 1) & 1, s = k & 1;
         const int th = ((py + 1) & 1) + 2 * r, tw = ((px + 1) & 1) + 2 * s;
-        if (n < cin) v = w[(((size_t)co * cin + n) * 4 + th) * 4 + tw];
+        if (n < cin) v = w4(co, n, th, tw);
     } else if (mode == AGAN_PACK_UP_FWD) {
         // cls = (py,px); k = (ci, r', s'); n = co
         const int py = cls >> 1, px = cls & 1, ci = k >> 2, r = (k >> 1) & 1, s = k & 1;
@@ -120,9 +123,8 @@ __device__ inline float packed_weight_value(const float* __restrict__ w, int mod
             int rl, rh, sl, sh;
             up_fwd_taps(py, r, rl, rh);
             up_fwd_taps(px, s, sl, sh);
-            const float* wp = w + ((size_t)n * cin + ci) * 9;
             for (int a = rl; a <= rh; ++a)
-                for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
+                for (int b = sl; b <= sh; ++b) v += w4(n, ci, a, b);
         }
     } else if (mode == AGAN_PACK_UP_DGRAD) {
         // k = (co, t, u) with t,u in 0..3; n = ci
@@ -131,13 +133,22 @@ __device__ inline float packed_weight_value(const float* __restrict__ w, int mod
             int rl, rh, sl, sh;
             up_dgrad_taps(t, rl, rh);
             up_dgrad_taps(u, sl, sh);
-            const float* wp = w + ((size_t)co * cin + n) * 9;
             for (int a = rl; a <= rh; ++a)
-                for (int b = sl; b <= sh; ++b) v += wp[a * 3 + b];
+                for (int b = sl; b <= sh; ++b) v += w4(co, n, a, b);
         }
     }
     return v;
 }
+struct GlobalOIHW {
+    const float* w;
+    int cin, kh, kw;
+    __device__ __forceinline__ float operator()(int co, int ci, int a, int b) const { return w[(((size_t)co * cin + ci) * kh + a) * kw + b]; }
+};
+__device__ inline float packed_weight_value(const float* __restrict__ w, int mode, int cls, int k, int n, int cout, int cin, int kh, int kw) {
+    return packed_weight_value_f(GlobalOIHW{w, cin, kh, kw}, mode, cls, k, n, cout, cin, kh, kw);
+}
+// does output column n run over the conv's OUTPUT channels (forward-type packs) or its input channels (data-gradient packs)?
+__host__ __device__ inline bool pack_n_is_cout(int mode) { return mode == AGAN_PACK_FWD || mode == AGAN_PACK_UP_FWD; }
 
 __host__ __device__ inline int pack_dims(int mode, int cout, int cin, int kh, int kw, int& ncls, int& K, int& N) {
     switch (mode) {
@@ -256,7 +267,8 @@ struct PatchPlan {
     int PW, PH, PHW, PP;                // patch width, height, positions per image, positions per tile
     int NPH, NT, IS;                    // phases (input parity sub-lattices), taps per phase, input step
     int nchunks, nstages, nsteps;       // 32-channel chunks; stages = chunks x phases; k-steps = stages x taps x 2
-    int tapoff[9];                      // LDS byte offset of each tap
+    int tapoff[9];                      // LDS byte offset of each tap (80-byte positions)
+    int tappos[9];                      // the same in positions
     int base_y[2][2], base_x[2][2];     // [output parity class][phase parity]: input coordinate of patch row/col 0 = IS * tile origin + base
     FastDiv dPP, dPHW, dPW;
 };

@@ -47,6 +47,11 @@ constexpr int kMaxPos = 320;        // positions a patch may have (host checks)
 constexpr int kPlaneBytes = kMaxPos * kPosBytes;
 constexpr int kItems = (kMaxPos * (kCH / 8) + 255) / 256;     // (position, channel octet) staging items per thread
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access (vmcnt(0)),
+// i.e. it would drain the patch prefetch and the weight-fragment ring at every stage; what the barriers of the second-generation
+// gather kernel protect is the LDS patch and nothing else.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ u32x4 buf_load_u4s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
@@ -293,6 +298,217 @@ __global__ __launch_bounds__(256, NPL == 1 ? AGAN_PATCH_OCC1 : 2) void conv_patc
         for (int r = 0; r < 16; ++r) {
             constexpr int dummy = 0; (void)dummy;
             const int nr = (r & 3) + 8 * (r >> 2);           // channel row of register r inside the block (+ 4*lh, per lane)
+            float v = acc[t][r];
+            if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
+            if (lrelu) v = v > 0.f ? v : 0.2f * v;
+            const unsigned so = (unsigned)nr * (unsigned)ohw * 4u;
+            const unsigned vo = (nfull || (nw + nr + 4 * lh < g.Cout)) ? voff : kOOB;
+            if (masked) v = buf_load_s(rmask, vo, so) > 0.f ? v : 0.2f * v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, so, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second generation of the gather kernel: the patch is DOUBLE-BUFFERED in LDS and the conversion + LDS store of the next stage's
+// patch is issued item by item BETWEEN the MFMA k-steps of the current stage (an MFMA occupies the vector issue port for 8 of
+// its 32 cycles, so the ~500 VALU instructions of a three-plane conversion disappear behind the matrix pipe instead of
+// standing between two barriers), which leaves ONE barrier per stage.  The three-plane mode stages 16 channels at a time (48-byte
+// positions: still an odd multiple of 16 B), so both buffers of a 4x32 tile take 59 KB and two workgroups share a CU.
+// LDS is dynamic: 2 buffers x planes x positions x position bytes for the geometry's real patch size.
+template <int ET, int NPL, int BN, int NT>
+__global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __restrict__ in, const unsigned short* __restrict__ wk,
+                                                             const float* __restrict__ bias, float* __restrict__ out, const Geom g,
+                                                             const PatchPlan pp, const int ksplit, const int stages_per_split,
+                                                             const size_t slab, const int act, const float* __restrict__ lrelu_mask,
+                                                             const int plane_bytes) {
+    constexpr int CHS = NPL >= 3 ? 16 : 32;                       // channels per stage
+    constexpr int PB = CHS * 2 + 16;                              // LDS bytes per position and plane
+    constexpr int HS = CHS / 16;                                  // 16-channel k-steps per tap
+    constexpr int SPS = NT * HS;                                  // k-steps per stage
+    constexpr int NI = (kMaxPos * (CHS / 8) + 255) / 256;         // staging items per thread
+    constexpr int U0 = SPS - NI;                                  // first k-step that carries a staging item
+    static_assert(U0 >= 0, "stage too short for its staging items");
+    constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char patch2[];
+    const int buf_bytes = NPL * plane_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int mt, nt, cls, split;
+    {
+        const int ncls = gridDim.z / ksplit, mtiles = gridDim.x, ntiles = gridDim.y;
+        int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * (int)gridDim.z);
+        nt = F % ntiles; F /= ntiles;
+        cls = F % ncls;  F /= ncls;
+        mt = F % mtiles; split = F / mtiles;
+    }
+    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int n0 = nt * BN;
+    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+    const int twl = pp.twl, thl = pp.thl;
+    const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+    const int ihw = g.IH * g.IW;
+    // stages of this kernel: (32-channel chunk, [16-channel half,] phase); the host counts stages in units of (chunk, phase)
+    const int nst = pp.nstages * (2 / HS);
+    const int stage_beg = split * stages_per_split * (2 / HS), stage_end = min(nst, stage_beg + stages_per_split * (2 / HS));
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const size_t wbytes_cls = (size_t)pp.nsteps * NPL * g.Nld * 32;
+    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)cls * wbytes_cls, wbytes_cls);
+
+    int it_iy[NI], it_ix[NI], it_cb[NI], it_oct[NI];
+    unsigned it_lds[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int oct = pp.dPP.div(e), p = e - oct * pp.PP;
+        const int pb = pp.dPHW.div(p), rem = p - pb * pp.PHW;
+        const int j = pp.dPW.div(rem), ii = rem - j * pp.PW;
+        const int b = tb0 + pb;
+        const bool ok = (oct < CHS / 8) & (b < g.B);
+        it_iy[i] = pp.IS * (ty0 + j);
+        it_ix[i] = pp.IS * (tx0 + ii);
+        it_cb[i] = ok ? (b * g.Cin + oct * 8) * ihw : -1;
+        it_oct[i] = oct;
+        it_lds[i] = (unsigned)(p * PB + oct * 16);
+    }
+    float sreg[NI][8];
+    const bool cin8 = (g.Cin & 7) == 0;
+
+    // stage -> (chunk32, half16, phase)
+    auto stage_parts = [&](int st, int& chunk, int& half, int& ph) {
+        if (HS == 2) { chunk = st / pp.NPH; ph = st - chunk * pp.NPH; half = 0; }
+        else { chunk = st / (2 * pp.NPH); const int rem = st - chunk * 2 * pp.NPH; half = rem / pp.NPH; ph = rem - half * pp.NPH; }
+    };
+    auto load_patch = [&](int st) {
+        int chunk, half, ph;
+        stage_parts(st, chunk, half, ph);
+        const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
+        const int c0 = chunk * 32 + half * 16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int iy = it_iy[i] + by, ix = it_ix[i] + bx;
+            const bool ok = (it_cb[i] >= 0) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            const int nrem = g.Cin - c0 - it_oct[i] * 8;
+            const unsigned voff = (ok & (nrem > 0)) ? (unsigned)(it_cb[i] + c0 * ihw + iy * g.IW + ix) * 4u : kOOB;
+            if (cin8) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, voff, (unsigned)(c * ihw) * 4u);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+            }
+        }
+    };
+    auto store_item = [&](int i, unsigned char* dstbuf) {
+        if (it_oct[i] < CHS / 8) {
+            u32x4 v[NPL];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned pl[NPL];
+                split_pack2<ET, NPL>(sreg[i][2 * c], sreg[i][2 * c + 1], pl);
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dstbuf + q * plane_bytes + it_lds[i]) = v[q];
+        }
+    };
+
+    unsigned lbase[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        lbase[t] = (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * PB + lh * 16);
+    }
+    const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    const unsigned wstep = (unsigned)(NPL * g.Nld * 32);
+    // k-step of the packed weights for (stage, tap, 16-channel sub-step)
+    auto qof = [&](int st, int tap, int hh) {
+        int chunk, half, ph;
+        stage_parts(st, chunk, half, ph);
+        return ((chunk * pp.NPH + ph) * NT + tap) * 2 + (HS == 2 ? hh : half);
+    };
+    u32x4 wf[2][NPL];
+    auto load_w = [&](int slot, int q) {
+        const unsigned so = (unsigned)min(q, pp.nsteps - 1) * wstep;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) wf[slot][p] = buf_load_u4s(rwk, wlane, so + (unsigned)(p * g.Nld * 32));
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (stage_beg < stage_end) {
+        load_w(0, qof(stage_beg, 0, 0));
+        load_w(1, SPS > 1 ? qof(stage_beg, 1 / HS, 1 % HS) : qof(min(stage_beg + 1, stage_end - 1), 0, 0));
+        load_patch(stage_beg);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) store_item(i, patch2 + (stage_beg & 1) * buf_bytes);
+        lds_barrier();
+        for (int stage = stage_beg; stage < stage_end; ++stage) {
+            const bool more = stage + 1 < stage_end;
+            const unsigned char* cur = patch2 + (stage & 1) * buf_bytes;
+            unsigned char* nxt = patch2 + ((stage + 1) & 1) * buf_bytes;
+            if (more) load_patch(stage + 1);
+#pragma unroll
+            for (int u = 0; u < SPS; ++u) {
+                const int t = u / HS, hh = u % HS;
+                u32x4 w[NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) w[p] = wf[u & 1][p];
+                {   // weights two k-steps ahead (possibly in the next stage)
+                    const int u2 = u + 2;
+                    const int st2 = u2 < SPS ? stage : min(stage + 1, stage_end - 1), uu = u2 < SPS ? u2 : u2 - SPS;
+                    load_w(u & 1, qof(st2, uu / HS, uu % HS));
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    u32x4 a[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p)
+                        a[p] = *reinterpret_cast<const u32x4*>(cur + p * plane_bytes + lbase[m] + (unsigned)(pp.tappos[t] * PB) + hh * 32);
+                    acc[m] = mfma_split<ET, NPL>(w, a, acc[m]);
+                }
+                if (u >= U0 && more) store_item(u - U0, nxt);      // next stage's patch, one item per k-step, behind the MFMAs
+            }
+            if (SPS & 1) {        // an odd number of k-steps per stage flips the parity of the two-slot weight ring: swap it back
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) { const u32x4 tmp = wf[0][p]; wf[0][p] = wf[1][p]; wf[1][p] = tmp; }
+            }
+            lds_barrier();
+        }
+    }
+
+    // ---- epilogue (as conv_patch_kernel) ----
+    const size_t ohw = (size_t)g.OH * g.OW;
+    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const bool add_bias = (bias != nullptr) && (ksplit == 1);
+    const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);
+    const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int nw = n0 + wn * 32;
+    const bool nfull = nw + 32 <= g.Cout;
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : dst, (size_t)g.Cout * sizeof(float));
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+        const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+        const unsigned pixoff = (unsigned)(b * g.Cout + nw + 4 * lh) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
+        const unsigned voff = pvalid ? pixoff * 4u : kOOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nr = (r & 3) + 8 * (r >> 2);
             float v = acc[t][r];
             if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
             if (lrelu) v = v > 0.f ? v : 0.2f * v;
@@ -561,30 +777,61 @@ __global__ __launch_bounds__(256) void unpack_patch_wgrad_kernel(const float* __
 // ================================================================================================
 // weight packing: OIHW -> [class][k-step][plane][Nld][16] 16-bit; k-step = ((chunk * NPH + phase) * NT + tap) * 2 + half
 // ================================================================================================
+// One workgroup packs 16 output columns x one 32-channel chunk for every class, phase and tap: the OIHW block those touch
+// ([16 co][32 ci][kh*kw] for the forward-type packs, [32 co][16 ci][kh*kw] for the data-gradient packs) is read with coalesced
+// row segments into LDS once, and each (k-step, plane) leaves as 16 rows x 32 B = 512 contiguous bytes.
+constexpr int kPackN = 16;
+struct TileOIHW {
+    const float* t;        // LDS tile [A][Bsz][kk]
+    int co0, ci0, A, Bsz, kh, kw;
+    __device__ __forceinline__ float operator()(int co, int ci, int a, int b) const {
+        const int ia = co - co0, ib = ci - ci0;
+        return ((unsigned)ia < (unsigned)A && (unsigned)ib < (unsigned)Bsz) ? t[(ia * Bsz + ib) * (kh * kw) + a * kw + b] : 0.f;
+    }
+};
 template <int ET, int NPL>
 __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout,
                                                                 int cin, int kh, int kw, int ncls, int Kin, int R, int S, int Nld,
                                                                 const PatchPlan pp) {
-    // one thread per (class, step, n, pair of channels)
-    const size_t total = (size_t)ncls * pp.nsteps * Nld * 8;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int j2 = (int)(e & 7);
-        size_t t = e >> 3;
-        const int n = (int)(t % Nld); t /= Nld;
-        const int q = (int)(t % pp.nsteps), cls = (int)(t / pp.nsteps);
-        const int half = q & 1, tq = q >> 1;
-        const int tap = tq % pp.NT, sq = tq / pp.NT, ph = sq % pp.NPH, chunk = sq / pp.NPH;
+    __shared__ float tile[kPackN * kCH * 16];
+    const int n0 = blockIdx.x * kPackN, chunk = blockIdx.y, c0 = chunk * kCH;
+    const int kk = kh * kw;
+    const bool ncout = pack_n_is_cout(mode);
+    TileOIHW T;
+    T.t = tile; T.kh = kh; T.kw = kw;
+    if (ncout) { T.co0 = n0; T.A = kPackN; T.ci0 = c0; T.Bsz = kCH; }
+    else       { T.co0 = c0; T.A = kCH; T.ci0 = n0; T.Bsz = kPackN; }
+    // rows of the tile are contiguous in OIHW: (Bsz * kk) floats starting at [co0 + a][ci0][0][0]
+    const int rowlen = T.Bsz * kk;
+    for (int i = threadIdx.x; i < T.A * rowlen; i += 256) {
+        const int a = i / rowlen, rem = i - a * rowlen;
+        const int co = T.co0 + a, ci = T.ci0 + rem / kk;
+        tile[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + T.ci0) * kk + rem] : 0.f;
+    }
+    __syncthreads();
+    const int nchan = Kin / (R * S);
+    const int sps = pp.NPH * pp.NT * 2;                     // k-steps of this chunk (per class)
+    const int total = ncls * sps * kPackN * 8;              // (class, step, row, channel pair)
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int j2 = e & 7, row = (e >> 3) & (kPackN - 1);
+        int t = e >> 7;
+        const int sq = t % sps, cls = t / sps;
+        const int half = sq & 1, tq = sq >> 1;
+        const int tap = tq % pp.NT, ph = tq / pp.NT;
         int r, s;
         if (pp.IS == 1) { r = tap / S; s = tap - r * S; }
         else { const int s2 = S / 2; r = 2 * (tap / s2) + (ph >> 1); s = 2 * (tap % s2) + (ph & 1); }
+        const int n = n0 + row;
+        if (n >= Nld) continue;
         float v[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int ci = chunk * kCH + half * 16 + j2 * 2 + c;
-            v[c] = ci < Kin / (R * S) ? packed_weight_value(w, mode, cls, (ci * R + r) * S + s, n, cout, cin, kh, kw) : 0.f;
+            const int ci = c0 + half * 16 + j2 * 2 + c;
+            v[c] = ci < nchan ? packed_weight_value_f(T, mode, cls, (ci * R + r) * S + s, n, cout, cin, kh, kw) : 0.f;
         }
         unsigned pl[NPL];
         split_pack2<ET, NPL>(v[0], v[1], pl);
+        const int q = chunk * sps + sq;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
             reinterpret_cast<unsigned*>(wk)[((((size_t)cls * pp.nsteps + q) * NPL + p) * Nld + n) * 8 + j2] = pl[p];
@@ -596,6 +843,22 @@ void launch_nt(const float* in, const void* wk, const float* bias, float* dst, c
                int act, const float* mask, hipStream_t st) {
     dim3 grid(pp.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
+    static const bool v1 = getenv("AGAN_PATCH_V1") != nullptr;
+    if (!v1) {
+        constexpr int PB = (NPL >= 3 ? 16 : 32) * 2 + 16;
+        const int plane = (pp.PP + 7) / 8 * 8 * PB;
+        const size_t smem = (size_t)2 * NPL * plane;
+        if (pp.NT == 9) {
+            static const hipError_t a9 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)a9;
+            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane);
+        } else {
+            static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)a4;
+            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane);
+        }
+        return;
+    }
     if (pp.NT == 9)
         hipLaunchKernelGGL((conv_patch_kernel<ET, NPL, BN, 9>), grid, dim3(256), 0, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask);
     else
@@ -684,6 +947,7 @@ PatchPlan make_patch_plan(const Geom& g) {
         const int r = t / cols, s = t - r * cols;
         const int ro = g.SY == 1 ? r * g.DY - dmin : r, so = g.SY == 1 ? s * g.DY - dmin : s;
         pp.tapoff[t] = (ro * pp.PW + so) * kPosBytes;
+        pp.tappos[t] = ro * pp.PW + so;
     }
     pp.nchunks = cdiv(g.Cin, kCH);
     pp.nstages = pp.nchunks * pp.NPH;
@@ -737,10 +1001,9 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
     pp.nstages = pp.nchunks * pp.NPH;
     pp.nsteps = pp.nstages * pp.NT * 2;
     const int Nld = agan_round_up(N, 32);
-    const size_t total = (size_t)ncls * pp.nsteps * Nld * 8;
-    const unsigned blocks = (unsigned)std::min<size_t>(cdivz(total, 256), 8192);
+    const dim3 blocks(cdiv(Nld, kPackN), pp.nchunks);
     unsigned short* o = static_cast<unsigned short*>(wk);
-#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), dim3(blocks), dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp)
+#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp)
     switch (prec) {
         case AGAN_PREC_BF16: AGAN_PK(0, 1); break;
         case AGAN_PREC_F16: AGAN_PK(1, 1); break;

@@ -77,10 +77,22 @@ def _run_oracle(gp, dps, ep, data, f, cap):
     return out
 
 
-def test_metric_config_step_vs_oracle():
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_metric_config_step_vs_oracle(mode):
+    """mode: the two fp32-grade arithmetic modes of the conv engine -- exact fp32 products on v_mfma_f32_32x32x2_f32, and
+    three bf16 planes / six v_mfma_f32_32x32x16_bf16 per product (24 mantissa bits) on the patch-resident kernels."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     HF = importlib.import_module("attention-gan_amd.backend.functional")
+    LIB = importlib.import_module("attention-gan_amd.backend.lib")
+    HF.set_precision(LIB.PRECISIONS[mode])
+    try:
+        _run_metric_parity(bench, HF, mode)
+    finally:
+        HF.set_precision(LIB.PREC_F32)
+
+
+def _run_metric_parity(bench, HF, mode):
     B = 24
     step = bench.build(torch.device(DEV), B, HF)
     gp = {k: v.detach().cpu().clone() for k, v in step.G.state_dict().items()}
@@ -147,10 +159,10 @@ def test_metric_config_step_vs_oracle():
         if not (direct or via64):
             bad.append(rows[-1])
     report = "\n".join(rows)
-    print(f"\nfull-size configs[2] step vs oracle: {len(rows)} tensors, {n_direct} within {RTOL:g} of the fp32 oracle, "
+    print(f"\nfull-size configs[2] step vs oracle [{mode}]: {len(rows)} tensors, {n_direct} within {RTOL:g} of the fp32 oracle, "
           f"{n_f64} by the fp64 rule, {len(bad)} failing\n" + report)
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "metric_parity_errors.txt"), "w") as f:
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"metric_parity_errors_{mode}.txt"), "w") as f:
         f.write(report + "\n")
     assert not bad, "tensors outside both bounds:\n" + "\n".join(bad)
     # forward quantities and losses never go through the fp64 rule
