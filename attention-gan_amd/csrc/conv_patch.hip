@@ -378,16 +378,29 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     float sreg[NI][8];
     const bool cin8 = (g.Cin & 7) == 0;
 
-    // stage -> (chunk32, half16, phase)
-    auto stage_parts = [&](int st, int& chunk, int& half, int& ph) {
-        if (HS == 2) { chunk = st / pp.NPH; ph = st - chunk * pp.NPH; half = 0; }
-        else { chunk = st / (2 * pp.NPH); const int rem = st - chunk * 2 * pp.NPH; half = rem / pp.NPH; ph = rem - half * pp.NPH; }
+    // stage -> (chunk32, half16, phase): decoded ONCE (an integer division by a runtime value costs ~25 instructions), then advanced
+    // by counters; wq = k-step of the packed weights of (stage, tap 0, sub-step 0)
+    struct Stage { int chunk, half, ph, wq; };
+    auto set_wq = [&](Stage& S) { S.wq = (S.chunk * pp.NPH + S.ph) * NT * 2 + (HS == 2 ? 0 : S.half); };
+    auto stage_of = [&](int st) {
+        Stage S;
+        if (HS == 2) { S.chunk = st / pp.NPH; S.ph = st - S.chunk * pp.NPH; S.half = 0; }
+        else { S.chunk = st / (2 * pp.NPH); const int rem = st - S.chunk * 2 * pp.NPH; S.half = rem / pp.NPH; S.ph = rem - S.half * pp.NPH; }
+        set_wq(S);
+        return S;
     };
-    auto load_patch = [&](int st) {
-        int chunk, half, ph;
-        stage_parts(st, chunk, half, ph);
-        const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
-        const int c0 = chunk * 32 + half * 16;
+    auto advance = [&](Stage S) {
+        if (++S.ph == pp.NPH) {
+            S.ph = 0;
+            if (HS == 2) ++S.chunk;
+            else if (++S.half == 2) { S.half = 0; ++S.chunk; }
+        }
+        set_wq(S);
+        return S;
+    };
+    auto load_patch = [&](const Stage& S) {
+        const int by = pp.base_y[py][S.ph >> 1], bx = pp.base_x[px][S.ph & 1];
+        const int c0 = S.chunk * 32 + S.half * 16;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int iy = it_iy[i] + by, ix = it_ix[i] + bx;
@@ -427,12 +440,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     }
     const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
     const unsigned wstep = (unsigned)(NPL * g.Nld * 32);
-    // k-step of the packed weights for (stage, tap, 16-channel sub-step)
-    auto qof = [&](int st, int tap, int hh) {
-        int chunk, half, ph;
-        stage_parts(st, chunk, half, ph);
-        return ((chunk * pp.NPH + ph) * NT + tap) * 2 + (HS == 2 ? hh : half);
-    };
+    // k-step of the packed weights for (stage, tap, 16-channel sub-step): taps are 2 k-steps apart, the sub-step is the low bit
+    auto qof = [&](const Stage& S, int tap, int hh) { return S.wq + tap * 2 + (HS == 2 ? hh : 0); };
     u32x4 wf[2][NPL];
     auto load_w = [&](int slot, int q) {
         const unsigned so = (unsigned)min(q, pp.nsteps - 1) * wstep;
@@ -447,43 +456,93 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (stage_beg < stage_end) {
-        load_w(0, qof(stage_beg, 0, 0));
-        load_w(1, SPS > 1 ? qof(stage_beg, 1 / HS, 1 % HS) : qof(min(stage_beg + 1, stage_end - 1), 0, 0));
-        load_patch(stage_beg);
+        Stage cs = stage_of(stage_beg);
+        load_w(0, qof(cs, 0, 0));
+        load_w(1, qof(cs, 1 / HS, 1 % HS));
+        load_patch(cs);
 #pragma unroll
         for (int i = 0; i < NI; ++i) store_item(i, patch2 + (stage_beg & 1) * buf_bytes);
         lds_barrier();
         for (int stage = stage_beg; stage < stage_end; ++stage) {
             const bool more = stage + 1 < stage_end;
+            const Stage ns = more ? advance(cs) : cs;
             const unsigned char* cur = patch2 + (stage & 1) * buf_bytes;
             unsigned char* nxt = patch2 + ((stage + 1) & 1) * buf_bytes;
-            if (more) load_patch(stage + 1);
+#if !defined(AGAN_PATCH_ABLATE) || AGAN_PATCH_ABLATE != 2
+            if (more) load_patch(ns);
+#endif
+            // pixel fragments are read ONE k-step ahead of the MFMAs that consume them (LDS latency and bank conflicts off the
+            // critical path); sched_group_barrier keeps that order in the emitted code
+            u32x4 af[2][TM][NPL];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    af[0][m][p] = *reinterpret_cast<const u32x4*>(cur + p * plane_bytes + lbase[m] + (unsigned)(pp.tappos[0] * PB));
 #pragma unroll
             for (int u = 0; u < SPS; ++u) {
-                const int t = u / HS, hh = u % HS;
                 u32x4 w[NPL];
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) w[p] = wf[u & 1][p];
-                {   // weights two k-steps ahead (possibly in the next stage)
+                {   // weights two k-steps ahead (possibly in the next stage; past the last stage: a harmless repeat)
                     const int u2 = u + 2;
-                    const int st2 = u2 < SPS ? stage : min(stage + 1, stage_end - 1), uu = u2 < SPS ? u2 : u2 - SPS;
-                    load_w(u & 1, qof(st2, uu / HS, uu % HS));
+#if !defined(AGAN_PATCH_ABLATE) || AGAN_PATCH_ABLATE != 3
+                    if (u2 < SPS) load_w(u & 1, qof(cs, u2 / HS, u2 % HS));
+                    else load_w(u & 1, qof(ns, (u2 - SPS) / HS, (u2 - SPS) % HS));
+#endif
                 }
+#if defined(AGAN_PATCH_ABLATE) && AGAN_PATCH_ABLATE == 5
+                if (false) {
+#else
+                if (u + 1 < SPS) {
+#endif
+                    const int t1 = (u + 1) / HS, h1 = (u + 1) % HS;
 #pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    u32x4 a[NPL];
+                    for (int m = 0; m < TM; ++m)
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p)
-                        a[p] = *reinterpret_cast<const u32x4*>(cur + p * plane_bytes + lbase[m] + (unsigned)(pp.tappos[t] * PB) + hh * 32);
-                    acc[m] = mfma_split<ET, NPL>(w, a, acc[m]);
+                        for (int p = 0; p < NPL; ++p)
+                            af[(u + 1) & 1][m][p] = *reinterpret_cast<const u32x4*>(cur + p * plane_bytes + lbase[m] + (unsigned)(pp.tappos[t1] * PB) + h1 * 32);
                 }
+#if defined(AGAN_PATCH_ABLATE) && AGAN_PATCH_ABLATE == 5
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[m] = mfma_split<ET, NPL>(w, af[0][m], acc[m]);
+#elif defined(AGAN_PATCH_ABLATE) && AGAN_PATCH_ABLATE == 6
+                // interleave the tiles' product chains: consecutive MFMAs never depend on each other
+                if (NPL == 3) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[2], af[u & 1][m][0], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[0], af[u & 1][m][2], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[1], af[u & 1][m][1], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[1], af[u & 1][m][0], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[0], af[u & 1][m][1], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma16<0>(w[0], af[u & 1][m][0], acc[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) acc[m] = mfma_split<ET, NPL>(w, af[u & 1][m], acc[m]);
+                }
+#else
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[m] = mfma_split<ET, NPL>(w, af[u & 1][m], acc[m]);
+#endif
+                __builtin_amdgcn_sched_group_barrier(0x100, TM * NPL, 0);                                  // next step's LDS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * (NPL == 1 ? 1 : (NPL == 2 ? 3 : 6)), 0);   // ... then this step's MFMAs
+#if !defined(AGAN_PATCH_ABLATE) || AGAN_PATCH_ABLATE != 1
                 if (u >= U0 && more) store_item(u - U0, nxt);      // next stage's patch, one item per k-step, behind the MFMAs
+#endif
             }
             if (SPS & 1) {        // an odd number of k-steps per stage flips the parity of the two-slot weight ring: swap it back
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) { const u32x4 tmp = wf[0][p]; wf[0][p] = wf[1][p]; wf[1][p] = tmp; }
             }
+#if !defined(AGAN_PATCH_ABLATE) || AGAN_PATCH_ABLATE != 4
             lds_barrier();
+#endif
+            cs = ns;
         }
     }
 
@@ -779,62 +838,114 @@ __global__ __launch_bounds__(256) void unpack_patch_wgrad_kernel(const float* __
 // ================================================================================================
 // One workgroup packs 16 output columns x one 32-channel chunk for every class, phase and tap: the OIHW block those touch
 // ([16 co][32 ci][kh*kw] for the forward-type packs, [32 co][16 ci][kh*kw] for the data-gradient packs) is read with coalesced
-// row segments into LDS once, and each (k-step, plane) leaves as 16 rows x 32 B = 512 contiguous bytes.
+// row segments into LDS once (tap-major, so the channel walk of the emit phase is conflict-free), and each (k-step, plane)
+// leaves as 16 rows x 32 B = 512 contiguous bytes.  The (class, phase, tap) loops are plain counters: no per-element decode.
 constexpr int kPackN = 16;
+constexpr int kPackTile = kPackN * kCH + 1;        // floats per tap plane of the LDS tile (+1: the fill walks taps across lanes)
 struct TileOIHW {
-    const float* t;        // LDS tile [A][Bsz][kk]
-    int co0, ci0, A, Bsz, kh, kw;
+    const float* t;        // LDS tile [kk][A][Bsz]
+    int co0, ci0, A, Bsz, kw;
     __device__ __forceinline__ float operator()(int co, int ci, int a, int b) const {
         const int ia = co - co0, ib = ci - ci0;
-        return ((unsigned)ia < (unsigned)A && (unsigned)ib < (unsigned)Bsz) ? t[(ia * Bsz + ib) * (kh * kw) + a * kw + b] : 0.f;
+        return ((unsigned)ia < (unsigned)A && (unsigned)ib < (unsigned)Bsz) ? t[(a * kw + b) * kPackTile + ia * Bsz + ib] : 0.f;
     }
 };
+// element (gathered channel ch, tap (r, s) of the GATHER geometry, output column n) of a pack mode, read through W4
+template <class W4>
+__device__ __forceinline__ float packed_value_direct(W4 w4, int mode, int cls, int ch, int r, int s, int n, int kh, int kw) {
+    switch (mode) {
+        case AGAN_PACK_FWD: return w4(n, ch, r, s);
+        case AGAN_PACK_DGRAD_S1: return w4(ch, n, kh - 1 - r, kw - 1 - s);
+        case AGAN_PACK_DGRAD_4x4S2: {
+            const int py = cls >> 1, px = cls & 1;
+            return w4(ch, n, ((py + 1) & 1) + 2 * r, ((px + 1) & 1) + 2 * s);
+        }
+        case AGAN_PACK_UP_FWD: {
+            int rl, rh, sl, sh;
+            up_fwd_taps(cls >> 1, r, rl, rh);
+            up_fwd_taps(cls & 1, s, sl, sh);
+            float v = 0.f;
+            for (int a = rl; a <= rh; ++a)
+                for (int b = sl; b <= sh; ++b) v += w4(n, ch, a, b);
+            return v;
+        }
+        default: {      // AGAN_PACK_UP_DGRAD
+            int rl, rh, sl, sh;
+            up_dgrad_taps(r, rl, rh);
+            up_dgrad_taps(s, sl, sh);
+            float v = 0.f;
+            for (int a = rl; a <= rh; ++a)
+                for (int b = sl; b <= sh; ++b) v += w4(ch, n, a, b);
+            return v;
+        }
+    }
+}
 template <int ET, int NPL>
 __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout,
                                                                 int cin, int kh, int kw, int ncls, int Kin, int R, int S, int Nld,
-                                                                const PatchPlan pp) {
-    __shared__ float tile[kPackN * kCH * 16];
+                                                                const PatchPlan pp, const FastDiv drow, const FastDiv dkk) {
+    __shared__ float tile[16 * kPackTile];
     const int n0 = blockIdx.x * kPackN, chunk = blockIdx.y, c0 = chunk * kCH;
     const int kk = kh * kw;
     const bool ncout = pack_n_is_cout(mode);
     TileOIHW T;
-    T.t = tile; T.kh = kh; T.kw = kw;
+    T.t = tile; T.kw = kw;
     if (ncout) { T.co0 = n0; T.A = kPackN; T.ci0 = c0; T.Bsz = kCH; }
     else       { T.co0 = c0; T.A = kCH; T.ci0 = n0; T.Bsz = kPackN; }
-    // rows of the tile are contiguous in OIHW: (Bsz * kk) floats starting at [co0 + a][ci0][0][0]
+    // rows of the block are contiguous in OIHW: (Bsz * kk) floats starting at [co0 + a][ci0][0][0]
     const int rowlen = T.Bsz * kk;
-    for (int i = threadIdx.x; i < T.A * rowlen; i += 256) {
-        const int a = i / rowlen, rem = i - a * rowlen;
-        const int co = T.co0 + a, ci = T.ci0 + rem / kk;
-        tile[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + T.ci0) * kk + rem] : 0.f;
+    const int nelem = T.A * rowlen;
+    for (int i0 = threadIdx.x; i0 < nelem; i0 += 256 * 8) {       // 8 independent loads in flight per thread
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 256;
+            const int a = drow.div(i), rem = i - a * rowlen;       // (multiply-high divisions: this loop is the kernel's ALU hot spot)
+            const int ib = dkk.div(rem), tap = rem - ib * kk;
+            const int co = T.co0 + a, ci = T.ci0 + ib;
+            dst[j] = i < nelem ? tap * kPackTile + a * T.Bsz + ib : -1;
+            v[j] = (i < nelem && co < cout && ci < cin) ? w[((size_t)co * cin + T.ci0) * kk + rem] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (dst[j] >= 0) tile[dst[j]] = v[j];
     }
     __syncthreads();
     const int nchan = Kin / (R * S);
-    const int sps = pp.NPH * pp.NT * 2;                     // k-steps of this chunk (per class)
-    const int total = ncls * sps * kPackN * 8;              // (class, step, row, channel pair)
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int j2 = e & 7, row = (e >> 3) & (kPackN - 1);
-        int t = e >> 7;
-        const int sq = t % sps, cls = t / sps;
-        const int half = sq & 1, tq = sq >> 1;
-        const int tap = tq % pp.NT, ph = tq / pp.NT;
-        int r, s;
-        if (pp.IS == 1) { r = tap / S; s = tap - r * S; }
-        else { const int s2 = S / 2; r = 2 * (tap / s2) + (ph >> 1); s = 2 * (tap % s2) + (ph & 1); }
-        const int n = n0 + row;
-        if (n >= Nld) continue;
-        float v[2];
+    // emit: thread = (one of 4 consecutive (class, phase, tap) slots, row, channel octet): 8 channels -> one 16-byte store per plane
+    const int sub = threadIdx.x >> 6, row = (threadIdx.x >> 2) & (kPackN - 1), oct = threadIdx.x & 3;
+    const int half = oct >> 1;
+    const int n = n0 + row;
+    const int ch = c0 + oct * 8;
+    const bool live = n < Nld;
+    const bool nvalid = n < (ncout ? cout : cin);
+    const int cols = pp.IS == 1 ? S : S / 2;                 // taps per phase row
+    const int nslots = ncls * pp.NPH * pp.NT;
+    for (int f0 = 0; f0 < nslots; f0 += 4) {
+        const int f = f0 + sub;
+        if (f >= nslots) break;                               // (wave-uniform: sub is the wave index)
+        const int tap = f % pp.NT, g2 = f / pp.NT, ph = g2 % pp.NPH, cls = g2 / pp.NPH;
+        const int tr = tap / cols, tc = tap - tr * cols;
+        const int r = pp.IS == 1 ? tr : 2 * tr + (ph >> 1), sx = pp.IS == 1 ? tc : 2 * tc + (ph & 1);
+        u32x4 o[NPL];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ci = c0 + half * 16 + j2 * 2 + c;
-            v[c] = ci < nchan ? packed_weight_value_f(T, mode, cls, (ci * R + r) * S + s, n, cout, cin, kh, kw) : 0.f;
+        for (int c2 = 0; c2 < 4; ++c2) {
+            float v[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                v[c] = (nvalid && ch + 2 * c2 + c < nchan) ? packed_value_direct(T, mode, cls, ch + 2 * c2 + c, r, sx, n, kh, kw) : 0.f;
+            unsigned pl[NPL];
+            split_pack2<ET, NPL>(v[0], v[1], pl);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) o[p][c2] = pl[p];
         }
-        unsigned pl[NPL];
-        split_pack2<ET, NPL>(v[0], v[1], pl);
-        const int q = chunk * sps + sq;
+        const int q = ((chunk * pp.NPH + ph) * pp.NT + tap) * 2 + half;
+        if (live) {
 #pragma unroll
-        for (int p = 0; p < NPL; ++p)
-            reinterpret_cast<unsigned*>(wk)[((((size_t)cls * pp.nsteps + q) * NPL + p) * Nld + n) * 8 + j2] = pl[p];
+            for (int p = 0; p < NPL; ++p)
+                reinterpret_cast<u32x4*>(wk)[((((size_t)cls * pp.nsteps + q) * NPL + p) * Nld + n) * 2 + (oct & 1)] = o[p];
+        }
     }
 }
 
@@ -1003,7 +1114,9 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
     const int Nld = agan_round_up(N, 32);
     const dim3 blocks(cdiv(Nld, kPackN), pp.nchunks);
     unsigned short* o = static_cast<unsigned short*>(wk);
-#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp)
+    const FastDiv dkk = make_fastdiv((unsigned)(kh * kw));
+    const FastDiv drow = make_fastdiv((unsigned)((pack_n_is_cout(mode) ? kCH : kPackN) * kh * kw));
+#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp, drow, dkk)
     switch (prec) {
         case AGAN_PREC_BF16: AGAN_PK(0, 1); break;
         case AGAN_PREC_F16: AGAN_PK(1, 1); break;

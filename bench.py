@@ -212,6 +212,52 @@ def cpu_baseline(batch, repeats=3):
                       f"({', '.join(f'{t:.1f}' for t in times)} s)"}
 
 
+def side_measurements(args, dev, HF, LIB, step, words, sent, reals, n=8):
+    """Short eager measurements reported BESIDE the headline, never inside it or its roofline:
+    random caption lengths 2..10 (the headline uses full-length captions), the other fp32-grade arithmetic mode, and the
+    end-to-end step with the Inception-v3-shaped trunk (stock MIOpen convs, random weights) as the DAMSM image encoder and the
+    bi-LSTM text encoder run on the device every step."""
+    def rate(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round(args.batch * n / (time.perf_counter() - t0), 1)
+    out = {"note": f"{n} eager steps each after 2 warm-up steps, same batch; images/s"}
+    B = args.batch
+    g = torch.Generator().manual_seed(99)
+    lens_r = torch.randint(2, T + 1, (B,), generator=g)
+    lens_r[0] = T
+    lens_r = lens_r.to(dev)
+    out["random_caption_lengths_2_10"] = rate(lambda: step.step(words, sent, lens_r, None, reals))
+    lens_full = torch.full((B,), T, dtype=torch.int64, device=dev)
+    other = "f32" if args.precision != "f32" else "bf16x6"
+    HF.set_precision(LIB.PRECISIONS[other])
+    try:
+        out[f"precision_{other}"] = rate(lambda: step.step(words, sent, lens_full, None, reals))
+    finally:
+        HF.set_precision(LIB.PRECISIONS[args.precision])
+    try:
+        RNN = importlib.import_module("attention-gan_amd.networks.rnn_encoder")
+        step2 = build(dev, B, HF, "inception")
+        rnn = RNN.RNNEncoder(vocabsize=1000, nhidden=EMB).to(dev).eval()
+        rnn.freeze_all_weights()
+        caps = torch.randint(1, 1000, (B, T), generator=g).to(dev)
+        lens_host = [T] * B
+
+        def e2e():
+            with torch.no_grad():
+                w_e, s_e = rnn(caps, lens_host)
+            return step2.step(w_e.contiguous(), s_e.contiguous(), lens_full, None, reals)
+        out["end_to_end_inception_trunk_plus_lstm"] = rate(e2e)
+    except Exception as exc:          # the side line must never cost the headline
+        out["end_to_end_inception_trunk_plus_lstm"] = f"failed: {type(exc).__name__}: {exc}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +275,9 @@ def main():
                     help="launch mode of the step: captured HIP graph replay or eager (auto: at 1 GPU probe both in the untimed warm-up and keep "
                          "the faster; eager under torch.distributed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the short side measurements reported beside the headline (random caption lengths, the fp32-MFMA mode, "
+                         "the end-to-end step with the Inception-shaped trunk and the LSTM text encoder)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented steps to this file")
     args = ap.parse_args()
@@ -373,6 +422,8 @@ def main():
                        "losses_finite": finite},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_variants:
+            line["variants"] = side_measurements(args, dev, HF, LIB, step, words, sent, reals)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
         print(json.dumps(line), flush=True)

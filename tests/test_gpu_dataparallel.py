@@ -49,11 +49,16 @@ def _worker(rank, world, port, q):
         G, Ds, enc = _nets(dev)
         step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=64 << 10)          # small buckets -> several exchanges per optimiser
         words, sent, lens, reals, noise, eps = _shard(rank, dev)
+        assert step.overlap_discriminators                                   # three D streams, each with its own exchange stream
         out = step.step(words, sent, lens, None, reals, noise, eps)
         torch.cuda.synchronize()
+        g_sd = {k: v.detach().cpu().numpy() for k, v in G.state_dict().items()}      # BEFORE the checkpoint-time buffer sync
+        d_sd = [{k: v.detach().cpu().numpy() for k, v in d.state_dict().items()} for d in Ds]
+        draw = torch.randn(4, device=dev, generator=step.rng).cpu().numpy()          # the per-rank noise generator
+        ckpt = step.state_dict()                                                    # averages BatchNorm statistics over the ranks
+        bufs = {k: v.detach().cpu().numpy() for k, v in ckpt["generator"].items() if "running" in k}
         # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
-        q.put((rank, {k: v.detach().cpu().numpy() for k, v in G.state_dict().items()},
-               [{k: v.detach().cpu().numpy() for k, v in d.state_dict().items()} for d in Ds], len(step.g_buckets.bounds)))
+        q.put((rank, g_sd, d_sd, len(step.g_buckets.bounds), draw, bufs))
     finally:
         dist.destroy_process_group()
 
@@ -70,8 +75,16 @@ def test_two_rank_step_equals_mean_of_shard_gradients():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    import numpy as np
+    draws, ckpt_bufs = [t[4] for t in got], [t[5] for t in got]
+    assert not np.array_equal(draws[0], draws[1])                     # replicas draw different z / eps (seed + rank)
+    differ = sum(not np.array_equal(got[0][1][k], got[1][1][k]) for k in got[0][1] if "running" in k)
+    assert differ > 0                                                 # per-replica BatchNorm statistics (local batches) ...
+    for k in ckpt_bufs[0]:                                            # ... are averaged into ONE checkpoint, identical on every rank
+        assert np.array_equal(ckpt_bufs[0][k], ckpt_bufs[1][k]), k
+        assert np.allclose(ckpt_bufs[0][k], 0.5 * (got[0][1][k] + got[1][1][k]), rtol=1e-6, atol=1e-7), k
     got = [(r, {k: torch.from_numpy(v) for k, v in g.items()}, [{k: torch.from_numpy(v) for k, v in d.items()} for d in ds], nb)
-           for r, g, ds, nb in got]
+           for r, g, ds, nb, _, _ in got]
     assert got[0][3] > 1                                              # more than one gradient bucket was exchanged
     for k, v in got[0][1].items():                                    # replicas end the step with identical weights
         if k.endswith((".weight", ".bias")):

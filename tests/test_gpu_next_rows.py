@@ -219,6 +219,126 @@ def test_config4_stage4_extension_vs_oracle_composition():
     assert all(torch.isfinite(q.grad).all() for q in G.parameters() if q.grad is not None)
 
 
+def _l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def test_config1_stage1_batch64_bf16():
+    """BASELINE.json configs[1] AS WRITTEN: stage-1 only (CA-net + gen1 + img_out1 + Disc64) at the real widths (gf 32, df 64,
+    emb 256, z = cond = 100), batch 64, conv operands rounded to bf16 (AGAN_PREC_BF16: v_mfma_f32_32x32x16_bf16, fp32
+    accumulate; BatchNorm statistics, GLU, losses and every tensor in HBM stay fp32), against the fp32 CPU oracle.
+
+    Tolerance (documented, not 1e-3): a bf16 operand carries 8 significant bits, so one product is off by ~2^-8 relative and a
+    K-term contraction by ~2^-8 / sqrt(K) of its terms' magnitude -- 2..3e-3 of a layer's output maximum (measured per layer in
+    test_gpu_parity.py) -- which the six conv layers of the stage-1 generator and BatchNorm's renormalisation carry to ~1e-2
+    at the image.  Bounds: image and losses 3e-2 of the maximum; gradients in relative L2 (a LeakyReLU kink that flips under
+    the perturbed forward is an O(1) pointwise change, see test_gpu_metric_parity.py) 2.5e-1.  Observed values are printed."""
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
+    GL = importlib.import_module("attention-gan_amd.losses.gen_loss").NonSaturatingGenLoss()
+    DL = importlib.import_module("attention-gan_amd.losses.disc_loss").NonSaturatingDiscLoss()
+    torch.manual_seed(21)
+    G = GEN.Generator(32, 256, 100, 100).to(DEV)
+    D = DISC.Disc64(64).to(DEV)
+    g = torch.Generator().manual_seed(21)
+    B = 64
+    noise, sent, eps = (torch.randn(B, n, generator=g) for n in (100, 256, 100))
+    real = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    gp = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    dp = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    gkeys = [k for k in gp if k.startswith(("vae.", "gen1.", "img_out1.")) and k.endswith((".weight", ".bias"))]
+    dkeys = O.trainable_keys(dp)
+    for k in gkeys:
+        gp[k].requires_grad_(True)
+    for k in dkeys:
+        dp[k].requires_grad_(True)
+    mu, logvar = O.vae_encode(sent, gp)
+    img_ref = O.gen_make_image(O.gen_initial_stage(noise, O.vae_reparam(mu, logvar, eps), gp, "gen1"), gp, "img_out1")
+    dloss_ref = O.ns_disc_loss(O.disc_forward(dp, real, 64), O.disc_forward(dp, img_ref.detach(), 64))
+    dgrads_ref = dict(zip(dkeys, torch.autograd.grad(dloss_ref, [dp[k] for k in dkeys])))
+    gloss_ref = O.ns_gen_loss(O.disc_forward(dp, img_ref, 64)) + O.kl_loss(mu, logvar)
+    ggrads_ref = dict(zip(gkeys, torch.autograd.grad(gloss_ref, [gp[k] for k in gkeys])))
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    HF.set_precision(L.PREC_BF16)
+    try:
+        cond, mu_d, lv_d = G.vae(sent.to(DEV), eps.to(DEV))
+        img = G.img_out1(G.gen1(noise.to(DEV), cond))
+        dloss = DL.get_loss(D, img.detach(), real.to(DEV))
+        dloss.backward()
+        dgr = {k: p.grad.clone() for k, p in D.named_parameters()}
+        D.zero_grad()
+        D.requires_grad_(False)
+        gloss = GL.get_loss(D, img) + KL(mu_d, lv_d)
+        gloss.backward()
+    finally:
+        HF.set_precision(L.PREC_F32)
+    e_img = float((img.detach().cpu() - img_ref.detach()).abs().max() / img_ref.detach().abs().max())
+    named = dict(G.named_parameters())
+    wg = max(_l2(named[k].grad, ggrads_ref[k]) for k in gkeys)
+    wd = max(_l2(dgr[k], dgrads_ref[k]) for k in dkeys)
+    print(f"configs[1] bf16 B=64: image max-rel {e_img:.2e} | d_loss {float(dloss):.5f} vs {float(dloss_ref):.5f} | g_loss {float(gloss):.5f} vs "
+          f"{float(gloss_ref):.5f} | worst G grad L2 {wg:.2e} | worst D grad L2 {wd:.2e}")
+    assert e_img <= 3e-2
+    assert abs(float(dloss) - float(dloss_ref)) <= 3e-2 * max(1.0, abs(float(dloss_ref)))
+    assert abs(float(gloss) - float(gloss_ref)) <= 3e-2 * max(1.0, abs(float(gloss_ref)))
+    assert wg <= 2.5e-1 and wd <= 2.5e-1
+
+
+def test_config4_stage4_batch8_f16():
+    """BASELINE.json configs[4] in its arithmetic: the 512x512 fourth stage + Disc512, batch 8, conv operands rounded to fp16
+    (AGAN_PREC_F16: v_mfma_f32_32x32x16_f16, fp32 accumulate).  No reference oracle exists for the extension (SURVEY.md section 8d
+    C5): the forward is held to the oracle's primitives composed alike, the backward to the fp32 mode of the same HIP path.
+
+    Tolerance: an fp16 operand carries 11 significant bits -> ~3e-4 of a layer's maximum per conv (test_gpu_parity.py), ~1e-2
+    after the 25 conv layers up to the 512x512 image; gradients in relative L2 for the LeakyReLU-kink reason.  fp16 also has a
+    NARROW RANGE: gradients below 6e-8 flush to zero and below 6e-5 lose bits.  The data gradients of this network at
+    initialisation sit around 1e-4..1e-6, inside that band, which is what the L2 bounds below price; a training run at this
+    precision would scale the loss (the reference has no such mode to be faithful to)."""
+    S4 = importlib.import_module("attention-gan_amd.networks.stage4")
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    torch.manual_seed(22)
+    G = S4.Generator4(8, 32, 16, 16).to(DEV)
+    D = S4.Disc512(8).to(DEV)
+    g = torch.Generator().manual_seed(22)
+    B, Tn = 8, 10
+    noise, sent, eps, words = torch.randn(B, 16, generator=g), torch.randn(B, 32, generator=g), torch.randn(B, 16, generator=g), torch.randn(B, 32, Tn, generator=g)
+    lens = [10, 7, 2, 10, 5, 3, 9, 6]
+    gp = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    mask = O.make_mask(lens)
+    mu, logvar = O.vae_encode(sent, gp)
+    h = O.gen_initial_stage(noise, O.vae_reparam(mu, logvar, eps), gp, "gen1")
+    for st in ("gen2", "gen3", "gen4"):
+        h, _ = O.gen_next_stage(h, words, mask, gp, st)
+    img512_ref = O.gen_make_image(h, gp, "img_out4")
+    res = {}
+    for mode in (L.PREC_F32, L.PREC_F16):
+        HF.set_precision(mode)
+        try:
+            G.load_state_dict({k: v.to(DEV) for k, v in gp.items() if k in G.state_dict()}, strict=False)   # same running stats each time
+            G.zero_grad(); D.zero_grad()
+            fakes, _, _, _ = G(noise.to(DEV), sent.to(DEV), words.to(DEV), mask.to(DEV), eps.to(DEV))
+            p = D(fakes[3])
+            (-torch.log(p + 1e-8).mean()).backward()
+            res[mode] = (fakes[3].detach().clone(), p.detach().clone(), {k: q.grad.clone() for k, q in G.named_parameters() if q.grad is not None})
+        finally:
+            HF.set_precision(L.PREC_F32)
+    e32 = float((res[L.PREC_F32][0].cpu() - img512_ref).abs().max() / img512_ref.abs().max())
+    e16 = float((res[L.PREC_F16][0].cpu() - img512_ref).abs().max() / img512_ref.abs().max())
+    worst = max(_l2(res[L.PREC_F16][2][k], res[L.PREC_F32][2][k]) for k in res[L.PREC_F32][2])
+    finite = all(torch.isfinite(v).all() for v in res[L.PREC_F16][2].values())
+    print(f"configs[4] 512x512 B=8: image vs oracle f32-mode {e32:.2e}, f16-mode {e16:.2e} | D512 out f16 vs f32 "
+          f"{float((res[L.PREC_F16][1] - res[L.PREC_F32][1]).abs().max()):.2e} | worst G grad L2 (f16 vs f32 mode) {worst:.2e}")
+    l16 = _l2(res[L.PREC_F16][0], img512_ref)
+    print(f"   f16-mode image relative L2 {l16:.2e}")
+    # (batch 8 at width 8: 30 train-mode BatchNorms over few samples and three softmax attentions amplify the 3e-4-per-layer
+    # rounding into isolated pixels ~1e-1 off while the image as a whole moves by ~1e-2: bounded in both norms)
+    assert e32 <= RTOL and finite
+    assert e16 <= 2e-1 and l16 <= 5e-2
+    assert worst <= 5e-1
+
+
 def test_hip_graph_replay_equals_eager_steps():
     """The whole step captured as one HIP graph (all streams, four fused Adam updates with device-resident step counters):
     warm-up + capture + replay must land where the same number of eager steps lands."""
