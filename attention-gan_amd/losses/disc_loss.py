@@ -42,7 +42,14 @@ class NonSaturatingDiscLoss(DiscLoss):
 
 
 class StandardDiscLoss(DiscLoss):
-    """BCE variant (disc_loss.py:26-47); not used by train.py:74-75 -- kept for API completeness, not a HIP kernel."""
+    """BCE variant (disc_loss.py:26-47); not used by train.py:74-75.  The discriminator passes run on the HIP kernels, the
+    cross-entropy over [B] probabilities is a stock ATen elementwise op."""
 
     def get_loss(self, discriminator: Module, fake_images: Tensor, real_images: Tensor) -> Tensor:
-        raise NotImplementedError("StandardDiscLoss is outside the AttnGAN hot path (train.py:75 uses NonSaturatingDiscLoss)")
+        """(BCE(D(G(z)), 0) + BCE(D(x), U(0.8, 1))) / 2 -- fake batch first, smoothed real labels (disc_loss.py:31-47)."""
+        bce = torch.nn.functional.binary_cross_entropy
+        p_fake = discriminator(fake_images)
+        loss_fake = bce(p_fake, self.make_labels_for_fake_imgs(p_fake.shape[0], device=p_fake.device))
+        p_real = discriminator(real_images)
+        loss_real = bce(p_real, self.make_labels_for_real_imgs(p_real.shape[0], device=p_real.device))
+        return (loss_fake + loss_real) / 2

@@ -24,5 +24,9 @@ class NonSaturatingGenLoss(GenLoss):
 
 
 class StandardGenLoss(GenLoss):
+    """BCE(D(G(z)), 1)  (gen_loss.py:21-35).  Not used by train.py:74; the discriminator runs on the HIP kernels, the
+    cross-entropy over its [B] probabilities is a stock ATen elementwise op."""
+
     def get_loss(self, discriminator: Module, fake_images: Tensor) -> Tensor:
-        raise NotImplementedError("StandardGenLoss is outside the AttnGAN hot path (train.py:74 uses NonSaturatingGenLoss)")
+        p = discriminator(fake_images)
+        return torch.nn.functional.binary_cross_entropy(p, self.make_labels_for_real_imgs(p.shape[0], device=p.device))

@@ -130,6 +130,11 @@ class FusedChain(nn.Module):
         return self.run(x)
 
 
+class _ReluChain(FusedChain):
+    def forward(self, x: Tensor) -> Tensor:
+        return torch.relu(self.run(x))
+
+
 class ResBlock(nn.Module):
     """conv3x3 C->2C, BN, GLU, conv3x3 C->C, BN, += x   (reference layers.py:156-176; keys block.{0,1,3,4}.*)."""
 
@@ -182,8 +187,10 @@ class Layers:
         return FusedChain().add_stage(1, HipConv2d(in_planes, out_planes * 2, 3, 1, 1, False, kind="up"), 2, L.ACT_GLU)
 
     @staticmethod
-    def upBlockReLU(in_planes: int, out_planes: int):
-        raise NotImplementedError("upBlockReLU is not used by the AttnGAN training path (SURVEY.md §2 #1)")
+    def upBlockReLU(in_planes: int, out_planes: int) -> FusedChain:
+        """Upsample(x2) -> conv3x3(in, out) -> BN -> ReLU (reference layers.py:71-80; unused by the training path): the folded
+        upsample conv and the fused BatchNorm of upBlock, followed by a stock ReLU."""
+        return _ReluChain().add_stage(1, HipConv2d(in_planes, out_planes, 3, 1, 1, False, kind="up"), 2, L.ACT_NONE)
 
     @staticmethod
     def downBlockLeakyReLU(in_planes: int, out_planes: int) -> FusedChain:

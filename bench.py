@@ -32,6 +32,7 @@ GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
 # bf16 peak although it issues three MFMAs per algorithmic product (its fraction can therefore not exceed 1/3)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0}
 # what the conv engine multiplies in, per --precision (fp32 storage and fp32 accumulate in every mode)
+MFMA_PRODUCTS = {"f32": 1, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6}
 DTYPE_NOTE = {"f32": "f32", "bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
 
 
@@ -75,7 +76,8 @@ class ConvTimer:
         tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
         if g.Cout <= 4:
             tile = "small_n"
-        name = f"conv_wgrad_{self.mode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
+        wmode = "f32" if self.mode == "bf16x6" else self.mode      # bf16x6 weight gradients run on the fp32 MFMA kernels
+        name = f"conv_wgrad_{wmode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
         # algorithmic HBM bytes of this call: gathered tensor + produced tensor + weights, each moved once (fp32)
         nbytes = 4.0 * (g.B * g.Cin * g.IH * g.IW + g.B * g.Cout * g.OH * g.OW + g.Cout * K * (g.OS * g.OS))
         e0, e1 = self._event(), self._event()
@@ -126,14 +128,19 @@ def baseline_metric_name():
         return "train images/sec at 256x256 stage-3, batch 24/GPU"
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch from the committed PMC run (profiles/r01_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 x2 read correction); None if that kernel was not measured."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f)["kernels"].get(kernel, {}).get("traffic")
-    except (OSError, ValueError, KeyError):
-        return None
+def measured_traffic(kernel, mode):
+    """HBM bytes per launch from the COMMITTED PMC passes, not from this run (profiles/r02_<mode>_traffic.json, made by
+    profiles/make_counters.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command; gfx950 x2 read correction);
+    None if that kernel was not measured."""
+    for name in (f"r02_{mode}_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)["kernels"].get(kernel, {}).get("traffic")
+            if t is not None:
+                return t
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def build(dev, batch, HF, encoder="standin"):
@@ -402,10 +409,17 @@ def main():
             achieved = falg / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": measured_traffic(name),
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": measured_traffic(name, args.precision),
+                        "traffic_source": "profiles/ (committed rocprofv3 PMC passes of this command), not this run",
                         "algorithmic_bytes_per_launch": round(nbytes / n),
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "timing": roofline_timing, "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),
                         "share_of_step_time": round((ms / ROOF_STEPS) / (elapsed / args.steps * 1e3), 3)}
+            products = MFMA_PRODUCTS[args.precision]
+            if products > 1:
+                # a split-precision mode issues `products` MFMAs per algorithmic multiply-add: the matrix pipe's own rate
+                roofline["mfma_products_per_multiply"] = products
+                roofline["mfma_issue_tflops"] = round(products * fexec / (ms * 1e-3) / 1e12, 1)
+                roofline["mfma_issue_frac"] = round(products * fexec / (ms * 1e-3) / 1e12 / peak, 4)
         line = {
             "metric": baseline_metric_name(),
             "value": round(world * args.batch * args.steps / elapsed, 3),

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Per-kernel-family counter evidence from rocprofv3 passes over bench.py (round 2).
+
+Collection (on the GPU box; counters in their own runs, kernel trace only; the program directly after `--`):
+
+    cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${MODE}_stats -o p -- $B
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
+              --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_mfma -o p -- $B
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_fetch -o p -- $B
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_write -o p -- $B
+
+    python profiles/make_counters.py gpurun_out/ev_${MODE} profiles r02_${MODE}
+
+Outputs  profiles/<tag>_kernel_stats.csv          (copy of rocprofv3's per-kernel time summary)
+         profiles/<tag>_kernel_family_counters.csv  one row per kernel family:
+              launches, avg duration (us, from the dispatch timestamps of the MFMA pass), share of the summed kernel time,
+              MFMA utilisation  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)
+                                  (busy cycles are summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs:
+                                   active cycles x 1024 / 8 SIMD-cycles were available -- MI355X_MICROARCH.md, DVFS / cycle constants),
+              MFMA MOPS (512-flop units) per launch,
+              HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies a 128-B request as 64 B;
+                                   calibrated for 16-B/lane streams, an upper bound for the 4-B/lane gathers) and the GB/s they imply
+         profiles/<tag>_traffic.json               bytes per launch of the conv kernel families: what bench.py reports as roofline.traffic
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+FAMILIES = [  # (family, substrings any of which selects the kernel)
+    ("conv_gather_patch16 (fwd/dgrad, 16-bit MFMA)", ["conv_patch_kernel"]),
+    ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
+    ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
+    ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
+    ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel"]),
+    ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel"]),
+    ("weight packs", ["pack_"]),
+    ("bn_stats_partial", ["bn_stats_partial"]),
+    ("bn_act_fwd (normalise + GLU/LeakyReLU)", ["bn_act_fwd_kernel"]),
+    ("bn_bwd_partial", ["bn_bwd_partial"]),
+    ("bn_bwd_apply", ["bn_bwd_apply"]),
+    ("bn_small (one-launch BatchNorm)", ["bn_small_"]),
+    ("bn finals", ["bn_stats_final", "bn_bwd_final", "bn_stats_rows"]),
+    ("attention fwd", ["attn_fwd_kernel", "attn_proj_kernel"]),
+    ("attention bwd", ["attn_bwd", "attn_dproj"]),
+    ("DAMSM losses", ["words_pair", "pair_slab_sum", "contrastive_ce", "sent_", "func_attn"]),
+    ("fused Adam", ["adam_"]),
+]
+
+
+def family_of(kernel):
+    for fam, pats in FAMILIES:
+        if any(p in kernel for p in pats):
+            return fam
+    return "other (ATen glue, activations, heads)"
+
+
+def bench_name(kernel, mode):
+    """the name bench.py's ConvTimer gives the kernel's launches (None for kernels it does not time)"""
+    for n in (128, 64, 32):
+        if f"conv_gather_f32_kernel<128, {n}" in kernel:
+            return f"conv_gather_f32_n{n}"
+    if "conv_wgrad_f32_kernel" in kernel:
+        return "conv_wgrad_f32"
+    if "conv_patch_wgrad_kernel" in kernel:
+        return f"conv_wgrad_{mode}"
+    if "conv_patch_kernel" in kernel:
+        for n in (128, 64, 32):
+            if f", {n}, 4>" in kernel or f", {n}, 9>" in kernel:
+                return f"conv_gather_{mode}_n{n}"
+    return None
+
+
+def read_pass(directory):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no counter_collection.csv under {directory}")
+    per_dispatch = {}
+    with open(files[0], newline="") as f:
+        for row in csv.DictReader(f):
+            d = per_dispatch.setdefault(row["Dispatch_Id"], {"kernel": row["Kernel_Name"], "t0": int(row["Start_Timestamp"]),
+                                                             "t1": int(row["End_Timestamp"]), "c": {}})
+            d["c"][row["Counter_Name"]] = d["c"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    return per_dispatch
+
+
+def main():
+    prefix, out_dir, tag = sys.argv[1:4]
+    mode = tag.split("_")[-1]
+    mfma, fetch, write = read_pass(prefix + "_mfma"), read_pass(prefix + "_fetch"), read_pass(prefix + "_write")
+    stats = glob.glob(os.path.join(prefix + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+    fam = {}
+    total_ns = 0
+    for d in mfma.values():
+        f = fam.setdefault(family_of(d["kernel"]), {"n": 0, "ns": 0, "busy": 0.0, "gui": 0.0, "mops": 0.0, "fetch": 0.0, "write": 0.0, "nf": 0, "nw": 0})
+        f["n"] += 1
+        f["ns"] += d["t1"] - d["t0"]
+        total_ns += d["t1"] - d["t0"]
+        f["busy"] += d["c"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        f["gui"] += d["c"].get("GRBM_GUI_ACTIVE", 0.0)
+        f["mops"] += d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+    conv = {}
+    for src, key, cnt in ((fetch, "fetch", "nf"), (write, "write", "nw")):
+        name = "FETCH_SIZE" if key == "fetch" else "WRITE_SIZE"
+        for d in src.values():
+            kb = d["c"].get(name, 0.0)
+            f = fam.setdefault(family_of(d["kernel"]), {"n": 0, "ns": 0, "busy": 0.0, "gui": 0.0, "mops": 0.0, "fetch": 0.0, "write": 0.0, "nf": 0, "nw": 0})
+            f[key] += kb * 1024
+            f[cnt] += 1
+            b = bench_name(d["kernel"], mode)
+            if b:
+                c = conv.setdefault(b, {"fetch": 0.0, "write": 0.0, "nf": 0, "nw": 0})
+                c[key] += kb * 1024
+                c[cnt] += 1
+    rows = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ns"]):
+        n = max(1, f["n"])
+        avg_us = f["ns"] / n / 1e3
+        traffic = (2 * f["fetch"] / max(1, f["nf"]) + f["write"] / max(1, f["nw"])) if (f["nf"] or f["nw"]) else 0.0
+        rows.append([name, f["n"], round(avg_us, 1), round(100.0 * f["ns"] / max(1, total_ns), 2),
+                     round(100.0 * f["busy"] / (f["gui"] * 128.0), 1) if f["gui"] else "",
+                     round(f["mops"] / n), round(traffic / 1e6, 2), round(traffic / (avg_us * 1e-6) / 1e9) if avg_us else ""])
+    with open(os.path.join(out_dir, f"{tag}_kernel_family_counters.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel_family", "launches", "avg_us", "pct_of_kernel_time", "mfma_util_pct", "mfma_mops_per_launch",
+                    "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s"])
+        w.writerows(rows)
+    kernels = {b: {"launches": max(c["nf"], c["nw"]), "fetch_size_raw": round(c["fetch"] / max(1, c["nf"])),
+                   "write_size": round(c["write"] / max(1, c["nw"])),
+                   "traffic": round(2 * c["fetch"] / max(1, c["nf"]) + c["write"] / max(1, c["nw"]))} for b, c in sorted(conv.items())}
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over `python bench.py --steps 2 "
+                     f"--warmup 1 --no-cpu-baseline --no-variants --graph off --precision {mode}`; summarised by profiles/make_counters.py",
+           "unit": "bytes per launch (average over all launches of the kernel in the run)",
+           "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH_SIZE + WRITE_SIZE; "
+                         "the x2 is calibrated for 16-B/lane streams, so it is an upper bound for the 4-B/lane patch loads",
+           "kernels": kernels}
+    with open(os.path.join(out_dir, f"{tag}_traffic.json"), "w") as fh:
+        json.dump(doc, fh, indent=1)
+    for r in rows:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()

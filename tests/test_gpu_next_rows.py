@@ -339,6 +339,36 @@ def test_config4_stage4_batch8_f16():
     assert worst <= 5e-1
 
 
+def test_standard_losses_and_upblock_relu():
+    """The step-API leftovers of SURVEY.md section 2 #1/#6: StandardGenLoss / StandardDiscLoss (gen_loss.py:21-35, disc_loss.py:26-47)
+    and Layers.upBlockReLU (layers.py:71-80) against the oracle's primitives + torch's BCE."""
+    LAYERS = importlib.import_module("attention-gan_amd.utilities.layers").Layers
+    GLm = importlib.import_module("attention-gan_amd.losses.gen_loss")
+    DLm = importlib.import_module("attention-gan_amd.losses.disc_loss")
+    torch.manual_seed(31)
+    D = DISC.Disc64(8).to(DEV)
+    g = torch.Generator().manual_seed(31)
+    real, fake = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1 for _ in range(2))
+    labels = torch.rand(4, generator=g) * 0.2 + 0.8
+    dp = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    bce = torch.nn.functional.binary_cross_entropy
+    dl = DLm.StandardDiscLoss()
+    dl.make_labels_for_real_imgs = lambda num_labels, label_smooth=0.8, device="cuda": labels.to(device)     # the reference draws U(0.8, 1)
+    got_d = dl.get_loss(D, fake.to(DEV), real.to(DEV))
+    pf, pr = O.disc_forward(dp, fake, 64), O.disc_forward(dp, real, 64)            # fake batch first (disc_loss.py:36-44)
+    assert_close(got_d, (bce(pf, torch.zeros(4)) + bce(pr, labels)) / 2, RTOL, "StandardDiscLoss")
+    got_g = GLm.StandardGenLoss().get_loss(D, fake.to(DEV))
+    assert_close(got_g, bce(O.disc_forward(dp, fake, 64), torch.ones(4)), RTOL, "StandardGenLoss")
+    got_g.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
+    blk = LAYERS.upBlockReLU(16, 8).to(DEV).train()
+    assert set(blk.state_dict()) == {"1.weight", "2.weight", "2.bias", "2.running_mean", "2.running_var", "2.num_batches_tracked"}
+    x = torch.randn(3, 16, 8, 8, generator=g)
+    p = {k: v.detach().cpu().clone() for k, v in blk.state_dict().items()}
+    ref = torch.relu(O.batchnorm_train(O.conv3x3(O.upsample2(x), p["1.weight"]), p, "2"))
+    assert_close(blk(x.to(DEV)), ref, RTOL, "upBlockReLU")
+
+
 def test_hip_graph_replay_equals_eager_steps():
     """The whole step captured as one HIP graph (all streams, four fused Adam updates with device-resident step counters):
     warm-up + capture + replay must land where the same number of eager steps lands."""
