@@ -12,6 +12,7 @@ from ctypes import byref, c_void_p
 from typing import Dict, Optional, Tuple
 
 import contextlib
+import weakref
 
 import torch
 from torch import Tensor
@@ -291,8 +292,73 @@ def set_launch_observer(obs) -> None:
     _OBSERVER[0] = obs
 
 
+# --------------------------------------------------------------------------------------------------------------
+# amax slots (AGAN_PREC_F16X3, include/agan.h).  The fp16 split mode needs max|x| of every tensor a conv gathers.  The kernel that
+# PRODUCES the tensor (BatchNorm forward / backward apply, a conv epilogue) folds that maximum into a small device slot while
+# it writes the tensor; the slot travels with the tensor OBJECT (autograd hands the same Python object from a producer Function
+# to its consumer, forward and backward) through an identity-keyed registry.  A tensor that arrives without a slot (torch.cat,
+# the image batch, a gradient autograd summed from two edges) gets one from agan_absmax: one extra read of that tensor.
+# Slots come from a zeroed arena window that amax_begin_step() opens (ONE fill launch per train step, graph-capturable);
+# outside a step every slot is its own torch.zeros.  Only LARGE tensors take the fused route (_AMAX_FUSE_MIN).
+# --------------------------------------------------------------------------------------------------------------
+_AMAX_REG: dict = {}
+_AMAX_ARENA: dict = {}            # device -> [arena tensor, window index, next slot, limit]
+_AMAX_WINDOW, _AMAX_WINDOWS = 1024, 4
+
+
+def amax_begin_step(device) -> None:
+    """Open a fresh zeroed window of amax slots for one train step (no-op unless the fp16 split mode is on)."""
+    if _PRECISION[0] != L.PREC_F16X3:
+        return
+    ent = _AMAX_ARENA.get(device)
+    if ent is None:
+        ent = _AMAX_ARENA[device] = [torch.zeros(_AMAX_WINDOWS * _AMAX_WINDOW * L.AMAX_SLOT, dtype=torch.float32, device=device), -1, 0, 0]
+    ent[1] = (ent[1] + 1) % _AMAX_WINDOWS
+    lo = ent[1] * _AMAX_WINDOW * L.AMAX_SLOT
+    ent[0][lo:lo + _AMAX_WINDOW * L.AMAX_SLOT].zero_()
+    ent[2], ent[3] = ent[1] * _AMAX_WINDOW, (ent[1] + 1) * _AMAX_WINDOW
+
+
+def _amax_new(device) -> Tensor:
+    ent = _AMAX_ARENA.get(device)
+    if ent is not None and ent[2] < ent[3]:
+        i = ent[2]
+        ent[2] += 1
+        return ent[0][i * L.AMAX_SLOT:(i + 1) * L.AMAX_SLOT]
+    return torch.zeros(L.AMAX_SLOT, dtype=torch.float32, device=device)
+
+
+def _amax_put(t: Tensor, slot: Tensor) -> None:
+    k = id(t)
+    _AMAX_REG[k] = (weakref.ref(t, lambda _r, k=k: _AMAX_REG.pop(k, None)), slot)
+
+
+def amax_of(t: Tensor) -> Tensor:
+    """the amax slot of a tensor: the one its producer filled, else a fresh one filled by agan_absmax"""
+    e = _AMAX_REG.get(id(t))
+    if e is not None and e[0]() is t:
+        return e[1]
+    slot = _amax_new(t.device)
+    L.call("agan_absmax", _p(t), t.numel(), _p(slot), _stream())
+    _amax_put(t, slot)
+    return slot
+
+
+_AMAX_FUSE_MIN = 1 << 22      # elements: below this a separate agan_absmax launch (~5 us) is as cheap as the fused commit
+
+
+def _amax_out(t: Tensor) -> Optional[Tensor]:
+    """slot for a kernel that is about to produce the LARGE tensor `t` (None unless the fp16 split mode is on): the producer folds
+    max|t| into it while it streams the tensor, which saves the consumer conv a second pass over tens of megabytes"""
+    if _PRECISION[0] != L.PREC_F16X3 or t.numel() < _AMAX_FUSE_MIN:
+        return None
+    slot = _amax_new(t.device)
+    _amax_put(t, slot)
+    return slot
+
+
 def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: Tensor, kind: str = "", phase: str = "",
-            act: int = 0, lrelu_mask: Optional[Tensor] = None, prec: int = L.PREC_F32) -> None:
+            act: int = 0, lrelu_mask: Optional[Tensor] = None, prec: int = L.PREC_F32, in_amax: Optional[Tensor] = None) -> None:
     lib = L.load()
     nbytes = lib.agan_conv_gather_ws_bytes(byref(g), prec)
     ws, wsp = _ws(nbytes, x)
@@ -300,8 +366,9 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
     obs = _OBSERVER[0]
     if obs is not None:
         obs.begin(kind, phase, g)
+    out_amax = _amax_out(out) if prec != L.PREC_F32 else None       # the 16-bit kernels fold max|out| into a slot as they store
     L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), prec, act, _p(lrelu_mask), wsp, nbytes,
-           _stream())
+           _stream(), _p(in_amax), _p(out_amax))
     if obs is not None:
         obs.end()
 
@@ -385,7 +452,9 @@ class _ConvFn(Function):
         out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
         pe = effective_precision(gf)
-        _gather(x, packed_weight(w, pf, cache, pe), b, gf, out, kind, "fwd", act, None, pe)
+        xs = amax_of(x) if pe == L.PREC_F16X3 else None               # (kept for the weight gradient)
+        _gather(x, packed_weight(w, pf, cache, pe), b, gf, out, kind, "fwd", act, None, pe, xs)
+        ctx.x_scale = xs
         if act == L.ACT_NONE:
             ctx.save_for_backward(x, w)
         else:                       # fused LeakyReLU: the backward needs the sign of the output
@@ -414,6 +483,13 @@ class _ConvFn(Function):
         gf, pf, gd, pd, _ = conv_geoms(ctx.kind, B, Cin, H, W, Cout, kh)
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        pe_d = effective_precision(gd) if ctx.needs_input_grad[0] else L.PREC_F32
+        # weight gradient: the mode that is set, except that the scaled fp16 split exists only on the patch kernels' geometries
+        pe_w = _PRECISION[0]
+        if pe_w == L.PREC_F16X3 and effective_precision(gf) != L.PREC_F16X3:
+            pe_w = L.PREC_F32
+        scaled_w = want_w and pe_w == L.PREC_F16X3
+        dys = amax_of(dy) if (pe_d == L.PREC_F16X3 or scaled_w) else None      # ONE slot of dy serves both gradients
         side = None
         if _WGRAD_SIDE[0] and want_w and ctx.wdst is not None and (not want_b or ctx.bdst is not None):
             kt = ktable(gf, x.device)                  # (tables are built on the forking stream)
@@ -430,8 +506,11 @@ class _ConvFn(Function):
                 obs = _OBSERVER[0]
                 if obs is not None:
                     obs.begin(ctx.kind, "wgrad", gf)
-                L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, _PRECISION[0], wacc, wsp, nbytes,
-                       _stream())
+                xs = None
+                if scaled_w:
+                    xs = ctx.x_scale if ctx.x_scale is not None else amax_of(x)
+                L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, pe_w, wacc, wsp, nbytes,
+                       _stream(), _p(xs), _p(dys if scaled_w else None))
                 if obs is not None:
                     obs.end()
             if want_b:
@@ -440,8 +519,8 @@ class _ConvFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             mask = x if ctx.handoff_in is not None else None       # x is the producer's LeakyReLU output
-            pe = effective_precision(gd)
-            _gather(dy, packed_weight(w, pd, ctx.cache, pe), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask, pe)
+            _gather(dy, packed_weight(w, pd, ctx.cache, pe_d), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask, pe_d,
+                    dys if pe_d == L.PREC_F16X3 else None)
             if mask is not None:
                 ctx.handoff_in.masked = True
         return dx, dw, db, None, None, None, None, None, None, None
@@ -514,11 +593,13 @@ class _BnActFn(Function):
             nbytes = lib.agan_bn_train_fwd_ws_bytes(Bg, C, HW)
             ws, wsp = _ws(nbytes, x)
             L.call("agan_bn_train_fwd", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
-                   _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, groups, wsp, nbytes, _stream())
+                   _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, groups, wsp, nbytes, _stream(),
+                   _p(_amax_out(out)))
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-            L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream())
+            L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream(),
+                   _p(_amax_out(out)))
         ctx.save_for_backward(x, g, b, mean, invstd)
         ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst, ctx.groups = act, training, residual is not None, gdst, bdst, groups
         return out
@@ -544,7 +625,7 @@ class _BnActFn(Function):
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(Bg, C, HW)
         ws, wsp = _ws(nbytes, x)
         L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
-               ctx.act, gacc, groups, wsp, nbytes, _stream())
+               ctx.act, gacc, groups, wsp, nbytes, _stream(), _p(_amax_out(dx)))
         dres = dout if ctx.has_res else None
         return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 

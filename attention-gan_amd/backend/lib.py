@@ -13,10 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AGAN_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libagan_hip.so")   # AGAN_LIB: kernel A/B builds
 
 # enums of include/agan.h
-PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_BF16X6 = 0, 1, 2, 3, 4
-PRECISIONS = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x6": PREC_BF16X6}
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4, 5
+PRECISIONS = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x6": PREC_BF16X6, "f16x3": PREC_F16X3}
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_4x4S2, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+AMAX_SLOT = 256        # floats per amax slot (include/agan.h: AGAN_AMAX_SLOT)
 
 
 class ConvGeom(Structure):
@@ -43,17 +44,18 @@ _SIGNATURES = {
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
-    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P]),
+    "agan_absmax": (c_int, [_P, c_size_t, _P, _P]),
     "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
-    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "agan_bias_grad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_bn_stats_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "agan_bn_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "agan_bn_train_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_bn_train_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_size_t, _P]),
-    "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_bn_train_fwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_size_t, _P, _P]),
+    "agan_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "agan_bn_act_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_bn_act_bwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "agan_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "agan_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "agan_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -76,6 +76,51 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- running |max| of a tensor for the fp16 split mode (include/agan.h: amax slots) ---------------------------------
+// A slot holds kAmaxLanes running maxima (zeroed by the caller before the producer runs); producers fold their maximum into one
+// of them (atomicMax on the bit pattern: non-negative floats order like unsigned integers), consumers take the maximum of all.
+constexpr int kAmaxLanes = 8;          // independent maxima per slot ...
+constexpr int kAmaxStride = 32;        // ... each on its own 128-byte line (floats): a slot is kAmaxLanes * kAmaxStride floats
+// One commit per WORKGROUP (256 threads): memory-side atomics on one line serialise at ~13 ns each (MI355X_MICROARCH.md, Global
+// float atomics), and even plain loads of one line queue at its L2 channel, so thousands of waves must not all touch the slot.
+// The workgroup's maximum is first compared with the running maximum through a relaxed agent-scope load (served by L2): only
+// a workgroup that RAISES it pays for the atomic -- after the first few hundred almost none does.
+__device__ __forceinline__ void amax_commit_lds(float m, float* slot, float* amax_red) {   // amax_red: 4 floats of LDS
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) amax_red[(threadIdx.x >> 6) & 3] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw && i < 4; ++i) m = fmaxf(m, amax_red[i]);
+        unsigned* p = reinterpret_cast<unsigned*>(slot) + (blockIdx.x & (kAmaxLanes - 1)) * kAmaxStride;
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+    }
+}
+__device__ __forceinline__ void amax_commit(float m, float* slot) {
+    __shared__ float amax_red[4];
+    amax_commit_lds(m, slot, amax_red);
+}
+__device__ __forceinline__ float amax_read(const float* slot) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < kAmaxLanes; ++i) m = fmaxf(m, slot[i * kAmaxStride]);
+    return m;
+}
+// power-of-two scale that lands amax in (2^12, 2^13]  (1 for an all-zero or non-finite tensor); *inv = 1 / scale
+__device__ __forceinline__ float amax_scale(float amax, float* inv) {
+    float s = 1.f, r = 1.f;
+    if (amax > 0.f && amax < INFINITY) {
+        int e;
+        frexpf(amax, &e);                                          // amax = f * 2^e, f in [0.5, 1)
+        e = max(-100, min(100, 13 - e));
+        s = ldexpf(1.f, e);
+        r = ldexpf(1.f, -e);
+    }
+    *inv = r;
+    return s;
+}
+
 // sum over a block of NT threads; result valid in every thread.  smem: NT/64 floats.
 template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* smem) {

@@ -10,9 +10,24 @@
 
 using namespace agan;
 
+#ifndef AGAN_ATTN_ABLATE
+#define AGAN_ATTN_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int kMaxC = 64;   // LDS budget for the projected words: kMaxC * TMAX floats
+constexpr int kAttLd = 68;  // row stride (floats) of the per-wave transposition tiles of the backward
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS traffic between the lanes of ONE wave needs no s_barrier (a wave's LDS instructions execute in order); this only stops the
+// compiler from moving LDS accesses across the hand-over.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // proj[b,c,t] = sum_e w[c,e] * words[b,e,t]        (attention.py:50-52: the 1x1 conv on the word axis)
 // one wave per (b, c): lanes stride the embedding axis, the T partial sums meet in one transposing butterfly
@@ -118,11 +133,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         da[t] = (live && t < T && dattn) ? dattn[((size_t)b * T + t) * HW + pp] : 0.f;
     }
     const float* dc = dctx ? dctx + (size_t)b * C * HW + pp : nullptr;
+    // Both channel loops are LATENCY bound as written one channel at a time (a dependent HBM round trip per iteration, ~6 waves per
+    // SIMD to hide it): they run kCU channels per trip with the next trip's loads already in flight.
+    constexpr int kCU = 4;
     if (dc) {
-        for (int c = 0; c < C; ++c) {
-            const float v = live ? dc[(size_t)c * HW] : 0.f;
+        float nx[kCU];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) da[t] += v * pj[c][t];
+        for (int j = 0; j < kCU; ++j) nx[j] = (live && j < C) ? dc[(size_t)j * HW] : 0.f;
+        for (int c0 = 0; c0 < C; c0 += kCU) {
+            float v[kCU];
+#pragma unroll
+            for (int j = 0; j < kCU; ++j) v[j] = nx[j];
+#pragma unroll
+            for (int j = 0; j < kCU; ++j) nx[j] = (live && c0 + kCU + j < C) ? dc[(size_t)(c0 + kCU + j) * HW] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kCU; ++j) {
+                if (c0 + j < C) {
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) da[t] += v[j] * pj[c0 + j][t];
+                }
+            }
         }
     }
     float dot = 0.f;
@@ -134,20 +164,104 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float* img = images + (size_t)b * C * HW + pp;
     float* di = dimages + (size_t)b * C * HW + pp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c < C; ++c) {
-        const float iv = live ? img[(size_t)c * HW] : 0.f;
-        const float dv = (live && dc) ? dc[(size_t)c * HW] : 0.f;
-        float s = 0.f;
+    if constexpr (TMAX == 16) {
+        // d(proj)[c][t] = sum over the pixels of dctx[c][p] attn[t][p] + images[c][p] ds[t][p] is a (channels x words x pixels) contraction
+        // whose reduction axis is the LANE axis.  As a butterfly it cost 17 cross-lane shuffles per channel and wave -- 270 of the
+        // kernel's 375 us at 128x128 (ablation).  Here each wave transposes its 64 pixels through a private LDS
+        // tile and lets v_mfma_f32_16x16x4_f32 reduce them: A[i = channel][k = pixel], B[k = pixel][j = word], 16 k-steps per term.
+        // Row stride kAttLd = 68 floats: the operand read of lane (i = l & 15, k = l >> 4) hits bank 4 i + k -- conflict-free.
+        float* Yw = reinterpret_cast<float*>(smem_raw + sizeof(float) * kMaxC * TMAX * 5) + wave * (48 * kAttLd);   // [2][16][kAttLd]: attn, ds
+        float* Xw = Yw + 32 * kAttLd;                                                                            // [16][kAttLd]: one term of 16 channels
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
-        if (live) di[(size_t)c * HW] = s;
-        float part[TMAX];
+        for (int t = 0; t < 16; ++t) {
+            Yw[t * kAttLd + lane] = a[t];
+            Yw[(16 + t) * kAttLd + lane] = ds[t];
+        }
+        wave_lds_sync();
+        const int mi = lane & 15, kq = lane >> 4;
+        float Ba[16], Bd[16];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) part[t] = dv * a[t] + iv * ds[t];
-        int t_own;
-        const float r = wave_sum_scatter<TMAX>(part, lane, t_own);       // TMAX + 1 shuffles per channel, not 6 * TMAX
-        if ((lane & (64 / TMAX - 1)) == 0) acc[wave][c][t_own] = r;
-    }
+        for (int k = 0; k < 16; ++k) {
+            Ba[k] = Yw[mi * kAttLd + 4 * k + kq];
+            Bd[k] = Yw[(16 + mi) * kAttLd + 4 * k + kq];
+        }
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            float ivr[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool on = live && c0 + j < C;
+                ivr[j] = on ? img[(size_t)(c0 + j) * HW] : 0.f;
+                Xw[j * kAttLd + lane] = (on && dc) ? dc[(size_t)(c0 + j) * HW] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = c0 + j;
+                if (c < C) {                                                     // workgroup-uniform
+                    float s = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
+                    if (live) di[(size_t)c * HW] = s;
+                }
+            }
+            wave_lds_sync();
+            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dp = __builtin_amdgcn_mfma_f32_16x16x4f32(Xw[mi * kAttLd + 4 * k + kq], Ba[k], dp, 0, 0, 0);
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Xw[j * kAttLd + lane] = ivr[j];
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dp = __builtin_amdgcn_mfma_f32_16x16x4f32(Xw[mi * kAttLd + 4 * k + kq], Bd[k], dp, 0, 0, 0);
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[wave][c0 + 4 * kq + r][mi] = dp[r];      // D[i = 4 (l >> 4) + r][j = l & 15]
+        }
+    } else {
+    float ivn[kCU], dvn[kCU];
+    #pragma unroll
+        for (int j = 0; j < kCU; ++j) {
+            ivn[j] = (live && j < C) ? img[(size_t)j * HW] : 0.f;
+            dvn[j] = (live && dc && j < C) ? dc[(size_t)j * HW] : 0.f;
+        }
+        for (int c0 = 0; c0 < C; c0 += kCU) {
+            float ivc[kCU], dvc[kCU];
+    #pragma unroll
+            for (int j = 0; j < kCU; ++j) {
+                ivc[j] = ivn[j];
+                dvc[j] = dvn[j];
+            }
+    #pragma unroll
+            for (int j = 0; j < kCU; ++j) {
+                const bool more = live && c0 + kCU + j < C;
+                ivn[j] = more ? img[(size_t)(c0 + kCU + j) * HW] : 0.f;
+                dvn[j] = (more && dc) ? dc[(size_t)(c0 + kCU + j) * HW] : 0.f;
+            }
+    #pragma unroll
+            for (int j = 0; j < kCU; ++j) {
+                const int c = c0 + j;
+                if (c >= C) break;                                               // workgroup-uniform
+                float s = 0.f;
+    #pragma unroll
+                for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
+                if (live) di[(size_t)c * HW] = s;
+    #if AGAN_ATTN_ABLATE != 1
+                float part[TMAX];
+    #pragma unroll
+                for (int t = 0; t < TMAX; ++t) part[t] = dvc[j] * a[t] + ivc[j] * ds[t];
+                int t_own;
+    #if AGAN_ATTN_ABLATE == 2
+                float r = 0.f; t_own = lane & (TMAX - 1);
+    #pragma unroll
+                for (int t = 0; t < TMAX; ++t) r += part[t];
+    #else
+                const float r = wave_sum_scatter<TMAX>(part, lane, t_own);       // TMAX + 1 shuffles per channel, not 6 * TMAX
+    #endif
+                if ((lane & (64 / TMAX - 1)) == 0) acc[wave][c][t_own] = r;
+    #endif
+            }
+        }
+}
     __syncthreads();
     float* dst = dproj_part + ((size_t)b * gridDim.x + blockIdx.x) * C * T;
     for (int i = threadIdx.x; i < C * T; i += 256) {
@@ -230,7 +344,7 @@ int agan_attn_bwd(const float* images, const float* words, const float* w, const
     dim3 grid(nblk, B);
 #define AGAN_ATTN_BWD(TM)                                                                                                            \
     do {                                                                                                                             \
-        const size_t smem_ = sizeof(float) * kMaxC * TM * 5;                                                                         \
+        const size_t smem_ = sizeof(float) * (kMaxC * TM * 5 + (TM == 16 ? 4 * 48 * kAttLd : 0));                                                                         \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TM>),                      \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_);                 \
         (void)attr_;                                                                                                                 \

@@ -134,10 +134,11 @@ template <int ACT, bool VEC>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ res,
-                                                         float* __restrict__ out, int B, int C, int HW) {
+                                                         float* __restrict__ out, int B, int C, int HW, float* __restrict__ amax) {
     constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
     const size_t total = (size_t)B * Co * HW / V;
+    float mx = 0.f;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t i = e * V;
         const int p = (int)(i % HW);
@@ -171,9 +172,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                 for (int k = 0; k < V; ++k) yv[k] += rv[k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < V; ++k) mx = fmaxf(mx, fabsf(yv[k]));
         if (VEC) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<float4*>(yv);
         else out[i] = yv[0];
     }
+    if (amax) amax_commit(mx, amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -275,10 +279,12 @@ template <int ACT, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ coef, float* __restrict__ dx, int B, int C, int HW) {
+                                                           const float* __restrict__ coef, float* __restrict__ dx, int B, int C, int HW,
+                                                           float* __restrict__ amax) {
     constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
     const size_t total = (size_t)B * Co * HW / V;
+    float mx = 0.f;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t i = e * V;
         const int p = (int)(i % HW);
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float dza, dzg;
             dz_of<ACT>(xa[k], xg[k], d[k], a, g, dza, dzg);
             oa[k] = a.s * (dza - c0 - (xa[k] - ma) * ia * c1);
-            if (ACT == AGAN_ACT_GLU) og[k] = g.s * (dzg - g0 - (xg[k] - mg) * ig * g1);
+            mx = fmaxf(mx, fabsf(oa[k]));
+            if (ACT == AGAN_ACT_GLU) { og[k] = g.s * (dzg - g0 - (xg[k] - mg) * ig * g1); mx = fmaxf(mx, fabsf(og[k])); }
         }
         if (VEC) {
             *reinterpret_cast<float4*>(dx + xi) = *reinterpret_cast<float4*>(oa);
@@ -315,6 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             if (ACT == AGAN_ACT_GLU) dx[xi + (size_t)Co * HW] = og[0];
         }
     }
+    if (amax) amax_commit(mx, amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -406,7 +414,8 @@ template <int ACT>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ res, float* __restrict__ out, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                           int64_t* __restrict__ nbt, int B, int C, int HW, float eps, float momentum) {
+                                                           int64_t* __restrict__ nbt, int B, int C, int HW, float eps, float momentum,
+                                                           float* __restrict__ amax) {
     __shared__ double red[2][4];
     constexpr bool GLU = ACT == AGAN_ACT_GLU;
     const int Co = GLU ? C / 2 : C;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         }
     }
     const float sa = gamma[c] * is, ta = beta[c] - (float)m * sa;
-    float sgs = 0.f, tg = 0.f;
+    float sgs = 0.f, tg = 0.f, mx = 0.f;
     if (GLU) { sgs = gamma[c + Co] * isg; tg = beta[c + Co] - mgf * sgs; }
 #pragma unroll
     for (int j = 0; j < kSmallPer; ++j) {
@@ -478,15 +487,18 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
             else if (ACT == AGAN_ACT_LRELU) z = z >= 0.f ? z : z * kSlope;
             if (!GLU && ACT == AGAN_ACT_NONE && res) z += res[oi];
             out[oi] = z;
+            mx = fmaxf(mx, fabsf(z));
         }
     }
+    if (amax) amax_commit(mx, amax);
 }
 
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int B, int C, int HW, int accumulate) {
+                                                           float* __restrict__ dbeta, int B, int C, int HW, int accumulate,
+                                                           float* __restrict__ amax) {
     __shared__ double red[2][4];
     constexpr bool GLU = ACT == AGAN_ACT_GLU;
     const int Co = GLU ? C / 2 : C;
@@ -532,16 +544,24 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         }
     }
     const float c0 = (float)(s0 / n), c1 = (float)(s1 / n), g0 = (float)(s2 / n), g1 = (float)(s3 / n);
+    float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < kSmallPer; ++j) {
         const int i = threadIdx.x + j * 256;
         if (i < n) {
             const int b = i / HW, p = i - b * HW;
             const size_t xi = ((size_t)b * C + c) * HW + p;
-            dx[xi] = a.s * (za[j] - c0 - (xa[j] - ma) * ia * c1);
-            if (GLU) dx[xi + (size_t)Co * HW] = g.s * (zg[j] - g0 - (xg[j] - mg) * ig * g1);
+            const float va = a.s * (za[j] - c0 - (xa[j] - ma) * ia * c1);
+            dx[xi] = va;
+            mx = fmaxf(mx, fabsf(va));
+            if (GLU) {
+                const float vg2 = g.s * (zg[j] - g0 - (xg[j] - mg) * ig * g1);
+                dx[xi + (size_t)Co * HW] = vg2;
+                mx = fmaxf(mx, fabsf(vg2));
+            }
         }
     }
+    if (amax) amax_commit(mx, amax);
 }
 
 int ew_blocks(size_t work) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(work, 256), 256 * 8)); }
@@ -578,7 +598,7 @@ int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, 
 }
 
 int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                    const float* residual, float* out, int B, int C, int HW, int act, void* stream) {
+                    const float* residual, float* out, int B, int C, int HW, int act, void* stream, float* out_amax) {
     AGAN_REQUIRE(x && mean && invstd && gamma && beta && out && B > 0 && C > 0 && HW > 0, "bn_act_fwd: bad argument");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_fwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
@@ -587,7 +607,7 @@ int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, cons
     const bool vec = (HW & 3) == 0;
     const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
     const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
-#define AGAN_L(A, V) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW)
+#define AGAN_L(A, V) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW, out_amax)
     if (act == AGAN_ACT_GLU) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
     else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
     else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
@@ -603,7 +623,7 @@ size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW) {
 
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
-                    int groups, void* ws, size_t ws_bytes, void* stream) {
+                    int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax) {
     AGAN_REQUIRE(x && dout && mean && invstd && gamma && beta && dx && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_bwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
@@ -622,7 +642,7 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
             const float* dg = dout + (size_t)gi * Bg * Co * HW;
             float* dxg = dx + (size_t)gi * Bg * C * HW;
             const int acc = gi == 0 ? accumulate : 1;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc)
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc, dx_amax)
             if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
             else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
             else AGAN_L(AGAN_ACT_NONE);
@@ -647,7 +667,7 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
         else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
         else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, Bg * HW, glu, dgamma, dbeta, coef, acc);
-#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW)
+#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW, dx_amax)
         if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
         else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
         else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
@@ -702,7 +722,7 @@ size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW) {
 
 int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
                       float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
-                      float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream) {
+                      float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax) {
     AGAN_REQUIRE(x && gamma && beta && out && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_train_fwd: bad argument");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_train_fwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
@@ -721,7 +741,7 @@ int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
             float* og = out + (size_t)gi * Bg * Co * HW;
             float* mg = mean + (size_t)gi * C;
             float* ig = invstd + (size_t)gi * C;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum)
+#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum, out_amax)
             if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
             else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
             else AGAN_L(AGAN_ACT_NONE);
@@ -735,7 +755,7 @@ int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
         float* ig = invstd + (size_t)gi * C;
         if (int e = agan_bn_stats(xg, Bg, C, HW, eps, mg, ig, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream)) return e;
         if (int e = agan_bn_act_fwd(xg, mg, ig, gamma, beta, residual ? residual + (size_t)gi * Bg * Co * HW : nullptr,
-                                    out + (size_t)gi * Bg * Co * HW, Bg, C, HW, act, stream))
+                                    out + (size_t)gi * Bg * Co * HW, Bg, C, HW, act, stream, out_amax))
             return e;
     }
     return AGAN_OK;

@@ -283,8 +283,9 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
                                                         const float* __restrict__ bias, int C, int HW,
                                                         float* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE,
-                                                        const float* __restrict__ lrelu_mask = nullptr) {
+                                                        const float* __restrict__ lrelu_mask = nullptr, float* __restrict__ amax = nullptr) {
     __shared__ float4 part[8][32];
+    float mx = 0.f;
     const size_t n4 = n / 4;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     for (size_t base = (size_t)blockIdx.x * 32; base < n4; base += (size_t)gridDim.x * 32) {
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
                 a.z = m.z > 0.f ? a.z : 0.2f * a.z; a.w = m.w > 0.f ? a.w : 0.2f * a.w;
             }
             *reinterpret_cast<float4*>(out + i * 4) = a;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
         }
         __syncthreads();
     }
@@ -346,7 +348,9 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
         if (act == AGAN_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
         if (lrelu_mask) a = lrelu_mask[q] > 0.f ? a : 0.2f * a;
         out[q] = a;
+        mx = fmaxf(mx, fabsf(a));
     }
+    if (amax) amax_commit(mx, amax);
 }
 
 template <int BN, int WM, int WN>
@@ -860,7 +864,8 @@ int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
 }
 
 int agan_conv_gather(const float* in, const void* wkv, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
-                     int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream) {
+                     int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream, const float* in_scale,
+                     float* out_amax) {
     const float* wk = static_cast<const float*>(wkv);
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
@@ -883,14 +888,15 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
         }
         float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
         timer_begin(st);
-        launch_patch_gather(in, wkv, bias, dst, g, pp, p, prec, act, lrelu_mask, st);
+        AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || in_scale != nullptr, "conv_gather: AGAN_PREC_F16X3 needs the operand's agan_absmax_scale pair");
+        launch_patch_gather(in, wkv, bias, dst, g, pp, p, prec, act, lrelu_mask, st, in_scale, out_amax);
         timer_end(st);
         if (int e = check_launch("conv_gather/patch")) return e;
         if (p.ksplit > 1) {
             const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
             const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
             hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
-                               bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask);
+                               bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask, out_amax);
             return check_launch("conv_gather/sum_slabs");
         }
         return AGAN_OK;
@@ -937,7 +943,8 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
 }
 
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
-                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream, const float* x_scale,
+                    const float* dy_scale) {
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
@@ -967,7 +974,8 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
         float* wsf = static_cast<float*>(ws);
         float* reduced = p.psplit > 1 ? wsf + p.slab * p.psplit : wsf;
         timer_begin(st);
-        launch_patch_wgrad(x, dy, wsf, g, pp, p, prec, st);
+        AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
+        launch_patch_wgrad(x, dy, wsf, g, pp, p, prec, st, x_scale, dy_scale);
         timer_end(st);
         if (int e = check_launch("conv_wgrad/patch")) return e;
         if (p.psplit > 1) {

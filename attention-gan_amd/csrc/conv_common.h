@@ -283,7 +283,8 @@ struct PatchWgrad {
 int prec_planes(int prec);
 PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec);
 void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
-                        hipStream_t st);
+                        hipStream_t st, const float* x_scale = nullptr, const float* dy_scale = nullptr);
+constexpr float kF16WeightScale = 2048.f;      // AGAN_PREC_F16X3 packs weights times 2^11 (|w| < 32 keeps fp16 finite)
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,
                                int accumulate, hipStream_t st);
 bool patch_supported(const Geom& g);
@@ -292,7 +293,8 @@ PatchGather plan_patch_gather(const Geom& g, const PatchPlan& pp);
 size_t patch_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
 int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, hipStream_t st);
 void launch_patch_gather(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp,
-                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st);
+                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st, const float* in_amax = nullptr,
+                         float* out_amax = nullptr);
 
 }  // namespace conv
 }  // namespace agan

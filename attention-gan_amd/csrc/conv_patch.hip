@@ -78,6 +78,14 @@ __device__ __forceinline__ void split_pack2(float a, float b, unsigned (&pl)[NPL
         pl[0] = pack2_rne<ET>(a, b);
     } else {
         // truncating splits: every remainder is exact, |x - sum of planes| < 2^-(8*NPL) |x|
+        if (ET == 1) {      // fp16 hi (round to nearest) + fp16 of the exact remainder: 22 mantissa bits
+            f32x2 v = {a, b};
+            const f16x2 h = __builtin_convertvector(v, f16x2);
+            const f32x2 hb = __builtin_convertvector(h, f32x2);
+            pl[0] = __builtin_bit_cast(unsigned, h);
+            pl[NPL - 1] = pack2_rne<1>(a - hb[0], b - hb[1]);
+            return;
+        }
         const unsigned a0 = __float_as_uint(a) & 0xFFFF0000u, b0 = __float_as_uint(b) & 0xFFFF0000u;
         pl[0] = pack_top16(a0, b0);
         const float ra = a - __uint_as_float(a0), rb = b - __uint_as_float(b0);
@@ -102,9 +110,9 @@ template <int ET, int NPL>
 __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&w)[NPL], const u32x4 (&a)[NPL], f32x16 c) {
     if (NPL == 1) return mfma16<ET>(w[0], a[0], c);
     if (NPL == 2) {
-        c = mfma16<0>(w[1], a[0], c);
-        c = mfma16<0>(w[0], a[1], c);
-        return mfma16<0>(w[0], a[0], c);
+        c = mfma16<ET>(w[1], a[0], c);
+        c = mfma16<ET>(w[0], a[1], c);
+        return mfma16<ET>(w[0], a[0], c);
     }
     c = mfma16<0>(w[NPL - 1], a[0], c);
     c = mfma16<0>(w[0], a[NPL - 1], c);
@@ -321,7 +329,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
                                                              const float* __restrict__ bias, float* __restrict__ out, const Geom g,
                                                              const PatchPlan pp, const int ksplit, const int stages_per_split,
                                                              const size_t slab, const int act, const float* __restrict__ lrelu_mask,
-                                                             const int plane_bytes) {
+                                                             const int plane_bytes, const float* __restrict__ in_amax,
+                                                             float* __restrict__ out_amax) {
+    constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3: operands scaled into fp16's range
+    float xs = 1.f, unscale = 1.f;                                // powers of two: exact
+    if (SCALED) {
+        float inv;
+        xs = amax_scale(amax_read(in_amax), &inv);
+        unscale = inv * (1.f / kF16WeightScale);
+    }
     constexpr int CHS = NPL >= 3 ? 16 : 32;                       // channels per stage
     constexpr int PB = CHS * 2 + 16;                              // LDS bytes per position and plane
     constexpr int HS = CHS / 16;                                  // 16-channel k-steps per tap
@@ -422,7 +438,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned pl[NPL];
-                split_pack2<ET, NPL>(sreg[i][2 * c], sreg[i][2 * c + 1], pl);
+                if (SCALED) split_pack2<ET, NPL>(sreg[i][2 * c] * xs, sreg[i][2 * c + 1] * xs, pl);
+                else split_pack2<ET, NPL>(sreg[i][2 * c], sreg[i][2 * c + 1], pl);
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
             }
@@ -557,6 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     const int nw = n0 + wn * 32;
     const bool nfull = nw + 32 <= g.Cout;
     const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : dst, (size_t)g.Cout * sizeof(float));
+    float omax = 0.f;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int l = (wm * TM + t) * 32 + l31;
@@ -569,13 +587,19 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
         for (int r = 0; r < 16; ++r) {
             const int nr = (r & 3) + 8 * (r >> 2);
             float v = acc[t][r];
+            if (SCALED) v *= unscale;
             if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
             if (lrelu) v = v > 0.f ? v : 0.2f * v;
             const unsigned so = (unsigned)nr * (unsigned)ohw * 4u;
             const unsigned vo = (nfull || (nw + nr + 4 * lh < g.Cout)) ? voff : kOOB;
             if (masked) v = buf_load_s(rmask, vo, so) > 0.f ? v : 0.2f * v;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, so, 0);
+            omax = fmaxf(omax, vo == kOOB ? 0.f : fabsf(v));
         }
+    }
+    if (out_amax != nullptr && ksplit == 1) {       // (a split launch: the slab sum commits it)
+        __syncthreads();                            // every wave is done with the patch: its LDS hosts the 4-float reduction
+        amax_commit_lds(omax, out_amax, reinterpret_cast<float*>(patch2));
     }
 }
 
@@ -610,7 +634,16 @@ template <int BJ> struct WgCfg {
 template <int ET, int NPL, int BJ, int NT>
 __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dst,
                                                                const Geom g, const PatchPlan pp, const int psplit, const int tiles_per_split,
-                                                               const size_t slab) {
+                                                               const size_t slab, const float* __restrict__ x_scale,
+                                                               const float* __restrict__ dy_scale) {
+    constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3 (x_scale / dy_scale: amax slots)
+    float xsc = 1.f, ysc = 1.f, unscale = 1.f;
+    if (SCALED) {
+        float ix, iy;
+        xsc = amax_scale(amax_read(x_scale), &ix);
+        ysc = amax_scale(amax_read(dy_scale), &iy);
+        unscale = ix * iy;
+    }
     using C = WgCfg<BJ>;
     constexpr int WJ = BJ / 32;                // waves along output channels
     constexpr int WT = 4 / WJ;                 // waves sharing the taps of a cout block
@@ -693,7 +726,8 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     unsigned pl[NPL];
-                    split_pack2<ET, NPL>(xr[i][2 * c], xr[i][2 * c + 1], pl);
+                    if (SCALED) split_pack2<ET, NPL>(xr[i][2 * c] * xsc, xr[i][2 * c + 1] * xsc, pl);
+                    else split_pack2<ET, NPL>(xr[i][2 * c], xr[i][2 * c + 1], pl);
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
                 }
@@ -709,7 +743,8 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned pl[NPL];
-                split_pack2<ET, NPL>(yr[i][2 * c], yr[i][2 * c + 1], pl);
+                if (SCALED) split_pack2<ET, NPL>(yr[i][2 * c] * ysc, yr[i][2 * c + 1] * ysc, pl);
+                else split_pack2<ET, NPL>(yr[i][2 * c], yr[i][2 * c + 1], pl);
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
             }
@@ -791,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = j0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            buf_store(ro, n < g.Cout ? (unsigned)(n * Kp + kcol) * 4u : kOOB, acc[t][r]);
+            buf_store(ro, n < g.Cout ? (unsigned)(n * Kp + kcol) * 4u : kOOB, SCALED ? acc[t][r] * unscale : acc[t][r]);
         }
     }
 }
@@ -936,7 +971,8 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
             for (int c = 0; c < 2; ++c)
                 v[c] = (nvalid && ch + 2 * c2 + c < nchan) ? packed_value_direct(T, mode, cls, ch + 2 * c2 + c, r, sx, n, kh, kw) : 0.f;
             unsigned pl[NPL];
-            split_pack2<ET, NPL>(v[0], v[1], pl);
+            if (ET == 1 && NPL == 2) split_pack2<ET, NPL>(v[0] * kF16WeightScale, v[1] * kF16WeightScale, pl);
+            else split_pack2<ET, NPL>(v[0], v[1], pl);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) o[p][c2] = pl[p];
         }
@@ -951,7 +987,7 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
 
 template <int ET, int NPL, int BN>
 void launch_nt(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,
-               int act, const float* mask, hipStream_t st) {
+               int act, const float* mask, hipStream_t st, const float* in_scale, float* out_amax) {
     dim3 grid(pp.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
     static const bool v1 = getenv("AGAN_PATCH_V1") != nullptr;
@@ -962,11 +998,11 @@ void launch_nt(const float* in, const void* wk, const float* bias, float* dst, c
         if (pp.NT == 9) {
             static const hipError_t a9 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)a9;
-            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane);
+            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
         } else {
             static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)a4;
-            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane);
+            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
         }
         return;
     }
@@ -977,19 +1013,20 @@ void launch_nt(const float* in, const void* wk, const float* bias, float* dst, c
 }
 template <int ET, int NPL>
 void launch_bn(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,
-               int act, const float* mask, hipStream_t st) {
-    if (p.bn == 128) launch_nt<ET, NPL, 128>(in, wk, bias, dst, g, pp, p, act, mask, st);
-    else if (p.bn == 64) launch_nt<ET, NPL, 64>(in, wk, bias, dst, g, pp, p, act, mask, st);
-    else launch_nt<ET, NPL, 32>(in, wk, bias, dst, g, pp, p, act, mask, st);
+               int act, const float* mask, hipStream_t st, const float* in_scale, float* out_amax) {
+    if (p.bn == 128) launch_nt<ET, NPL, 128>(in, wk, bias, dst, g, pp, p, act, mask, st, in_scale, out_amax);
+    else if (p.bn == 64) launch_nt<ET, NPL, 64>(in, wk, bias, dst, g, pp, p, act, mask, st, in_scale, out_amax);
+    else launch_nt<ET, NPL, 32>(in, wk, bias, dst, g, pp, p, act, mask, st, in_scale, out_amax);
 }
 
 template <int ET, int NPL, int BJ>
-void launch_wg_nt(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st) {
+void launch_wg_nt(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st,
+                  const float* xs = nullptr, const float* ys = nullptr) {
     dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
     if (pp.NT == 9)
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab);
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
     else
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab);
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
 }
 
 inline int pow2ceil_log(int v) {
@@ -1000,13 +1037,35 @@ inline int pow2ceil_log(int v) {
 
 }  // namespace
 
+namespace {
+// max |x| folded into an amax slot (agan_common.h: amax_commit); the slot is zero on entry
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ slot) {
+    float m = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    amax_commit(m, slot);
+}
+}  // namespace
+
+extern "C" int agan_absmax(const float* x, size_t n, float* amax_slot, void* stream) {
+    AGAN_REQUIRE(x && amax_slot && n > 0, "absmax: bad argument");
+    AGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: tensor must be 16-byte aligned");
+    const unsigned blocks = (unsigned)std::min<size_t>(cdivz(n / 4 + 1, 256 * 8), 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, amax_slot);
+    return check_launch("absmax");
+}
+
 namespace agan {
 namespace conv {
 
 int prec_planes(int prec) {
     switch (prec) {
         case AGAN_PREC_BF16: case AGAN_PREC_F16: return 1;
-        case AGAN_PREC_BF16X3: return 2;
+        case AGAN_PREC_BF16X3: case AGAN_PREC_F16X3: return 2;
         case AGAN_PREC_BF16X6: return 3;
     }
     return 0;
@@ -1122,6 +1181,7 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
         case AGAN_PREC_F16: AGAN_PK(1, 1); break;
         case AGAN_PREC_BF16X3: AGAN_PK(0, 2); break;
         case AGAN_PREC_BF16X6: AGAN_PK(0, 3); break;
+        case AGAN_PREC_F16X3: AGAN_PK(1, 2); break;
         default: return AGAN_EINVAL;
     }
 #undef AGAN_PK
@@ -1147,8 +1207,9 @@ PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec) {
 }
 
 void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
-                        hipStream_t st) {
+                        hipStream_t st, const float* x_scale, const float* dy_scale) {
     switch (prec) {
+        case AGAN_PREC_F16X3: if (p.bj == 128) launch_wg_nt<1, 2, 128>(x, dy, part, g, pp, p, st, x_scale, dy_scale); else launch_wg_nt<1, 2, 64>(x, dy, part, g, pp, p, st, x_scale, dy_scale); break;
         case AGAN_PREC_BF16: if (p.bj == 128) launch_wg_nt<0, 1, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<0, 1, 64>(x, dy, part, g, pp, p, st); break;
         case AGAN_PREC_F16: if (p.bj == 128) launch_wg_nt<1, 1, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<1, 1, 64>(x, dy, part, g, pp, p, st); break;
         case AGAN_PREC_BF16X3: if (p.bj == 128) launch_wg_nt<0, 2, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<0, 2, 64>(x, dy, part, g, pp, p, st); break;
@@ -1164,12 +1225,14 @@ void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, i
 }
 
 void launch_patch_gather(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp,
-                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st) {
+                         const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st, const float* in_amax,
+                         float* out_amax) {
     switch (prec) {
-        case AGAN_PREC_BF16: launch_bn<0, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
-        case AGAN_PREC_F16: launch_bn<1, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
-        case AGAN_PREC_BF16X3: launch_bn<0, 2>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
-        default: launch_bn<0, 3>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st); break;
+        case AGAN_PREC_BF16: launch_bn<0, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st, nullptr, out_amax); break;
+        case AGAN_PREC_F16: launch_bn<1, 1>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st, nullptr, out_amax); break;
+        case AGAN_PREC_BF16X3: launch_bn<0, 2>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st, nullptr, out_amax); break;
+        case AGAN_PREC_F16X3: launch_bn<1, 2>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st, in_amax, out_amax); break;
+        default: launch_bn<0, 3>(in, wk, bias, dst, g, pp, p, act, lrelu_mask, st, nullptr, out_amax); break;
     }
 }
 

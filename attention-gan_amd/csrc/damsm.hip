@@ -11,6 +11,13 @@
 
 using namespace agan;
 
+#ifndef AGAN_PAIR_UNROLL_N
+#define AGAN_PAIR_UNROLL_N 4
+#endif
+#define AGAN_PRAGMA_(x) _Pragma(#x)
+#define AGAN_PRAGMA(x) AGAN_PRAGMA_(x)
+#define AGAN_PAIR_UNROLL AGAN_PRAGMA(unroll AGAN_PAIR_UNROLL_N)
+
 namespace {
 
 constexpr int kNT = 320;      // threads per pair workgroup (5 waves): >= S and >= D
@@ -37,8 +44,13 @@ struct PairSmem {
 // Forward of a pair.  On return (after the trailing barrier): sm.e, sm.a2, sm.c, sm.cosv/num/n1/n2 are valid;
 // a1[] holds thread r's first-softmax row (valid for r < S).
 template <int TMAX, int DR>
-__device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float* __restrict__ fj, const float* __restrict__ ei,
-                                             int D, int T, int S, int L, float scale, float gamma1, float eps, float (&a1)[TMAX]) {
+__device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float* __restrict__ fj, const float* __restrict__ fjT,
+                                             const float* __restrict__ ei, int D, int T, int S, int L, float scale, float gamma1,
+                                             float eps, float (&a1)[TMAX]) {
+    // fjT: the same features transposed to [S][D] (or null).  A thread that owns a CHANNEL walks the regions; on the NCHW layout
+    // its wave touches 64 different 128-byte lines per load and the 15 resident waves of a CU evict each other's lines from the
+    // 32 KB L1 long before a lane has used the other 31 floats of its line (measured: the pair backward spent two thirds of its
+    // 318 us in the two channel-owned loops).  On the transposed copy the same load is one 256-byte wave access.
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     // 1. caption words into LDS
@@ -53,6 +65,7 @@ __device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float
 #pragma unroll
     for (int w = 0; w < TMAX; ++w) a1[w] = 0.f;
     if (rlive) {
+AGAN_PAIR_UNROLL
         for (int d = 0; d < D; ++d) {
             const float fv = fj[(size_t)d * S + r];
 #pragma unroll
@@ -99,9 +112,16 @@ __device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float
         float acc[TMAX];
 #pragma unroll
         for (int w = 0; w < TMAX; ++w) acc[w] = 0.f;
+        #ifdef AGAN_PAIR_NO_T
         const float* fr = fj + (size_t)tid * S;
+        const int fs = 1;
+#else
+        const float* fr = fjT ? fjT + tid : fj + (size_t)tid * S;
+        const int fs = fjT ? D : 1;
+#endif
+AGAN_PAIR_UNROLL
         for (int q = 0; q < S; ++q) {
-            const float fv = fr[q];
+            const float fv = fr[(size_t)q * fs];
 #pragma unroll
             for (int w = 0; w < TMAX; ++w) acc[w] += fv * sm.a2[q][w];
         }
@@ -127,7 +147,8 @@ __device__ __forceinline__ void pair_forward(PairSmem<TMAX, DR>& sm, const float
 }
 
 template <int TMAX, int DR>
-__global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
+__global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ featT,
+                                                             const float* __restrict__ wemb,
                                                              const int64_t* __restrict__ lens, float gamma1, float gamma2, float gamma3,
                                                              float* __restrict__ sim, float* __restrict__ maps, int B, int D, int T, int S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -135,7 +156,8 @@ __global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __rest
     const int j = blockIdx.x, i = blockIdx.y;      // image j, caption i
     const int L = min((int)lens[i], T);
     float a1[TMAX];
-    pair_forward<TMAX, DR>(sm, feat + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L, rsqrtf((float)D), gamma1, 1e-8f, a1);
+    pair_forward<TMAX, DR>(sm, feat + (size_t)j * D * S, featT + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L,
+                           rsqrtf((float)D), gamma1, 1e-8f, a1);
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w]);     // words_loss.py:77-79
@@ -188,8 +210,11 @@ __global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const i
     }
 }
 
+// (the <12, 256> instance: 43 KB of LDS = three pair workgroups per CU only if the 15 waves also fit the register file, i.e.
+// four waves per SIMD -> at most 128 VGPRs; left alone the compiler takes 136 and the last 64 of 576 pairs wait for a second round)
 template <int TMAX, int DR>
-__global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ wemb,
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(TMAX <= 12 ? 4 : 2))) void words_pair_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ featT,
+                                                             const float* __restrict__ wemb,
                                                              const int64_t* __restrict__ lens, const float* __restrict__ dS,
                                                              const float* __restrict__ dloss, float gamma1, float gamma2, float gamma3,
                                                              float* __restrict__ part_f, float* __restrict__ part_w, int B, int D, int T, int S) {
@@ -211,8 +236,9 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const float scale = rsqrtf((float)D), eps = 1e-8f;
     const float* fj = feat + (size_t)j * D * S;
+    const float* fjT = featT + (size_t)j * D * S;
     float a1[TMAX];
-    pair_forward<TMAX, DR>(sm, fj, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
+    pair_forward<TMAX, DR>(sm, fj, fjT, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
 
     // --- d cos, then d num / d n1 / d n2 per word (uniform, recomputed by every thread from LDS) ---
     float dnum[TMAX], dn1[TMAX], dn2[TMAX];
@@ -258,6 +284,7 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
 #pragma unroll
     for (int w = 0; w < TMAX; ++w) { da2[w] = 0.f; a2r[w] = rlive ? sm.a2[r][w] : 0.f; }
     if (rlive) {
+AGAN_PAIR_UNROLL
         for (int d = 0; d < D; ++d) {
             const float fv = fj[(size_t)d * S + r];
 #pragma unroll
@@ -308,9 +335,16 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
     __syncthreads();
     // --- thread d: de[d][w] += sum_r ds[r][w] f[d][r];  dwemb[i][d][w] += de ---
     if (tid < D) {
+#ifdef AGAN_PAIR_NO_T
         const float* fr = fj + (size_t)tid * S;
+        const int fs = 1;
+#else
+        const float* fr = fjT + tid;
+        const int fs = D;
+#endif
+AGAN_PAIR_UNROLL
         for (int q = 0; q < S; ++q) {
-            const float fv = fr[q];
+            const float fv = fr[(size_t)q * fs];
 #pragma unroll
             for (int w = 0; w < TMAX; ++w) de[w] += fv * sm.a2[q][w];
         }
@@ -319,6 +353,20 @@ __global__ __launch_bounds__(kNT) void words_pair_bwd_kernel(const float* __rest
         for (int w = 0; w < TMAX; ++w)
             if (w < T) dwi[w] = w < L ? de[w] : 0.f;
     }
+}
+
+// featT[b][s][d] = feat[b][d][s]: 32x32 tiles through LDS, both sides coalesced (7 MB at the metric shapes)
+__global__ __launch_bounds__(256) void feat_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int D, int S) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, d0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (size_t)b * D * S;
+    float* dst = out + (size_t)b * D * S;
+    for (int k = ty; k < 32; k += 8)
+        tile[k][tx] = (d0 + k < D && s0 + tx < S) ? src[(size_t)(d0 + k) * S + s0 + tx] : 0.f;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (s0 + k < S && d0 + tx < D) dst[(size_t)(s0 + k) * D + d0 + tx] = tile[tx][k];
 }
 
 // out[row][e] = sum_k part[row][k][e], k = 0..B-1 in order (row = image for dfeat, caption for dwemb)
@@ -400,7 +448,7 @@ __global__ __launch_bounds__(kNT) void func_attn_fwd_kernel(const float* __restr
     PairSmem<TMAX>& sm = *reinterpret_cast<PairSmem<TMAX>*>(smem_raw);
     const int b = blockIdx.x;
     float a1[TMAX];
-    pair_forward<TMAX, kNT>(sm, context + (size_t)b * D * S, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
+    pair_forward<TMAX, kNT>(sm, context + (size_t)b * D * S, nullptr, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
     if (threadIdx.x < D)
         for (int w = 0; w < L; ++w) wctx[((size_t)b * D + threadIdx.x) * L + w] = sm.c[threadIdx.x][w];
     if (threadIdx.x < S)
@@ -423,7 +471,7 @@ __global__ __launch_bounds__(kNT) void func_attn_bwd_kernel(const float* __restr
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* fb = context + (size_t)b * D * S;
     float a1[TMAX];
-    pair_forward<TMAX, kNT>(sm, fb, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
+    pair_forward<TMAX, kNT>(sm, fb, nullptr, query + (size_t)b * D * L, D, L, S, L, scale, gamma1, 1e-8f, a1);
     if (tid < D) {
 #pragma unroll
         for (int w = 0; w < TMAX; ++w) sm.c[tid][w] = (dwctx && w < L) ? dwctx[((size_t)b * D + tid) * L + w] : 0.f;
@@ -509,7 +557,7 @@ inline void allow_ce_smem() {      // (once per process: one process drives one 
 
 extern "C" {
 
-size_t agan_words_loss_save_elems(int B, int D, int T, int S) { return (size_t)B * B; }
+size_t agan_words_loss_save_elems(int B, int D, int T, int S) { return (size_t)B * B + (size_t)B * D * S; }   // dS, transposed features
 
 int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, float gamma1,
                         float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps, float* save, int B,
@@ -520,13 +568,15 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     AGAN_REQUIRE(T >= 1 && T <= 32, "words_loss: seq_len %d > 32", T);
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);
+    float* featT = save + (size_t)B * B;              // [B][S][D], kept for the backward
+    hipLaunchKernelGGL(feat_transpose_kernel, dim3(cdiv(S, 32), cdiv(D, 32), B), dim3(256), 0, st, feat, featT, D, S);
 #define AGAN_PAIR_FWD(TM, DRR)                                                                                                          \
     do {                                                                                                                               \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<TM, DRR>),             \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<TM, DRR>()); \
         (void)attr_;                                                                                                                   \
         const size_t smem_ = pair_smem_bytes<TM, DRR>();                                                                               \
-        hipLaunchKernelGGL((words_pair_fwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, wemb, lens, gamma1,  \
+        hipLaunchKernelGGL((words_pair_fwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, featT, wemb, lens, gamma1,  \
                            gamma2, gamma3, sim, attn_maps, B, D, T, S);                                                                \
     } while (0)
     if (T <= 12 && D <= 256) AGAN_PAIR_FWD(12, 256);
@@ -562,7 +612,7 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_smem_bytes<TM, DRR>()); \
         (void)attr_;                                                                                                                   \
         const size_t smem_ = pair_smem_bytes<TM, DRR>();                                                                               \
-        hipLaunchKernelGGL((words_pair_bwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, wemb, lens, save,   \
+        hipLaunchKernelGGL((words_pair_bwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, save + (size_t)B * B, wemb, lens, save,   \
                            dloss, gamma1, gamma2, gamma3, part_f, part_w, B, D, T, S);                                                 \
     } while (0)
     if (T <= 12 && D <= 256) AGAN_PAIR_BWD(12, 256);

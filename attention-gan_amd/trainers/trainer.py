@@ -176,6 +176,8 @@ class GanTrainStep(ModelTrainer):
             # copy up front -- a blocking H2D copy in the middle of the step drains the launch pipeline (~4 ms per step)
             host = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1)
             lengths = host.pin_memory().to(word_embs.device, non_blocking=True)
+        if word_embs.is_cuda:
+            HF.amax_begin_step(word_embs.device)        # zeroed amax slots of this step (fp16 split mode only; one fill launch)
         prev_side = HF.set_wgrad_side_stream(self.overlap_weight_gradients and word_embs.is_cuda)
         try:
             return self._step(word_embs, sent_embs, lengths, class_ids, real_imgs, noise, eps)

@@ -30,10 +30,10 @@ if ROOT not in sys.path:
 GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (spec): f32 = v_mfma_f32_32x32x2_f32; bf16x3 is priced against the
 # bf16 peak although it issues three MFMAs per algorithmic product (its fraction can therefore not exceed 1/3)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0}
 # what the conv engine multiplies in, per --precision (fp32 storage and fp32 accumulate in every mode)
-MFMA_PRODUCTS = {"f32": 1, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6}
-DTYPE_NOTE = {"f32": "f32", "bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
+MFMA_PRODUCTS = {"f32": 1, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
+DTYPE_NOTE = {"f32": "f32", "bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3", "bf16x6": "bf16x6", "f16x3": "f16x3"}
 
 
 def algorithmic_conv_flops(kind, B, Cin, H, W, Cout, k):
@@ -271,7 +271,7 @@ def main():
     ap.add_argument("--steps", type=int, default=120, help="timed steps (default: a >= 3 s timed region at the metric config)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=24, help="images per GPU (metric: 24)")
-    ap.add_argument("--precision", choices=["f32", "bf16x6", "bf16x3", "bf16", "f16"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "bf16x3", "bf16", "f16"], default="f32",
                     help="MFMA mode of the conv engine: f32 = exact fp32 products (v_mfma_f32_32x32x2_f32); bf16x6 = three bf16 planes, "
                          "6 MFMAs per product (fp32-grade); bf16x3 = two planes, 3 MFMAs; bf16 / f16 = operands rounded to 16 bits "
                          "(BASELINE configs[1] / configs[4] arithmetic)")

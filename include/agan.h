@@ -40,8 +40,11 @@ enum {
     AGAN_PREC_BF16 = 1,   /* operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (BASELINE configs[1])                 */
     AGAN_PREC_BF16X3 = 2, /* bf16 hi/lo split (16 mantissa bits), 3 MFMAs per product                                 */
     AGAN_PREC_F16 = 3,    /* operands rounded to fp16, v_mfma_f32_32x32x16_f16 (BASELINE configs[4])                  */
-    AGAN_PREC_BF16X6 = 4  /* bf16 hi/mid/lo split (24 mantissa bits), 6 MFMAs per product: fp32-grade products at 2.67x
+    AGAN_PREC_BF16X6 = 4, /* bf16 hi/mid/lo split (24 mantissa bits), 6 MFMAs per product: fp32-grade products at 2.67x
                              the fp32-MFMA rate                                                                       */
+    AGAN_PREC_F16X3 = 5   /* fp16 hi/lo split (22 mantissa bits), 3 MFMAs per product, operands scaled by powers of two into
+                             fp16's range: fp32-grade products at 5.3x the fp32-MFMA rate.  The gathered operand's scale comes
+                             from an amax slot (see agan_absmax below), the weights are packed times 2^11                   */
 };
 /* The 16-bit modes run on the patch-resident kernels (csrc/conv_patch.hip), which take 3x3 / 2x2-per-class stride-1 and 4x4
  * stride-2 geometries with more than 4 output channels and images of at least 4x4; any other call (linear layers, the RGB
@@ -117,7 +120,17 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
  * mask > 0, else 0.2 -- the backward of the LeakyReLU that produced this conv's forward input (the mask is that input), folded
  * into the epilogue so that the activation's backward needs no pass of its own. */
 int agan_conv_gather(const float* in, const void* wk, const float* bias, float* out, const agan_conv_geom* g,
-                     const int32_t* ktable, int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream);
+                     const int32_t* ktable, int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream,
+                     const float* in_amax /* AGAN_PREC_F16X3: amax slot of `in`; NULL otherwise */,
+                     float* out_amax /* optional: amax slot that receives max|out| (16-bit MFMA paths) */);
+
+/* amax slots (AGAN_PREC_F16X3).  The fp16 split mode scales each gathered operand by the power of two that lands its largest
+ * magnitude in (2^12, 2^13]; the kernels derive that scale themselves from an AMAX SLOT: AGAN_AMAX_SLOT floats of device memory,
+ * ZEROED by the caller, into which the kernel that PRODUCES a tensor folds max|value| (the `*_amax` arguments of the BatchNorm
+ * and conv entry points: no extra pass over the tensor), or which agan_absmax fills for a tensor that has no such producer.
+ * Everything stays on the device and on the stream: no host sync, HIP-graph capturable. */
+#define AGAN_AMAX_SLOT 256    /* 8 running maxima, each on its own 128-byte line */
+int agan_absmax(const float* x, size_t n, float* amax_slot, void* stream);
 
 /* conv weight gradient: x is the forward input, dy the gradient of the forward output, g the FORWARD geometry.
  * Produces dw in OIHW [cout][cin][kh][kw] (pack mode AGAN_PACK_FWD or AGAN_PACK_UP_FWD says how g was built).
@@ -125,7 +138,8 @@ int agan_conv_gather(const float* in, const void* wk, const float* bias, float* 
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
 /* accumulate != 0: dw += gradient (a parameter used twice in one backward, e.g. D on the real and the fake batch). */
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
-                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                    int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                    const float* x_amax, const float* dy_amax /* AGAN_PREC_F16X3: amax slots of x and dy; NULL otherwise */);
 
 /* dbias[n] = sum_{b,y,x} dy[b,n,y,x]  (bias of nn.Linear / outlogits conv: generator_submodules.py:152, discriminators.py:15) */
 int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, int accumulate, void* stream);
@@ -143,7 +157,7 @@ int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, 
                   void* ws, size_t ws_bytes, void* stream);
 /* y = act(gamma*(x-mean)*invstd+beta) [+ residual].  GLU halves the channels (out has C/2).  residual may be NULL. */
 int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                    const float* residual, float* out, int B, int C, int HW, int act, void* stream);
+                    const float* residual, float* out, int B, int C, int HW, int act, void* stream, float* out_amax);
 /* Training-mode forward in one call: batch statistics (written to mean/invstd for the backward, folded into the running
  * statistics) + normalise + activation.  Tensors with B*HW <= 8192 per channel run as ONE launch (a workgroup per channel
  * keeps the channel in registers between the two phases); larger ones as agan_bn_stats + agan_bn_act_fwd.
@@ -154,12 +168,12 @@ int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, cons
 size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW);
 int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
                       float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, int HW,
-                      float eps, float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream);
+                      float eps, float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax);
 /* backward: dx[B,C,HW], dgamma[C], dbeta[C] from dout (C/2 channels under GLU); gamma/beta gradients are summed over the groups. */
 size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
-                    int groups, void* ws, size_t ws_bytes, void* stream);
+                    int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax);
 /* plain activations without BN (first D conv + LeakyReLU layers.py:139-140; tanh generator_submodules.py:137) */
 int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream);
 int agan_act_bwd(const float* out, const float* dout, float* dx, size_t n, int act, void* stream);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: bash profiles/collect_evidence.sh MODE   (on the GPU box, from the repo root; writes gpurun_out/r02_${MODE}_*: copy those into profiles/)
+MODE=$1
+R=$GRAFT_REPO_ROOT
+case $MODE in f16*) LOWC=SQ_INSTS_VALU_MFMA_MOPS_F16;; *) LOWC=SQ_INSTS_VALU_MFMA_MOPS_BF16;; esac
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${MODE}_stats -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_mfma -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_fetch -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_write -o p -- $B > /dev/null 2>&1 &&
+cd $R && python3 profiles/make_counters.py gpurun_out/ev_${MODE} gpurun_out r02_${MODE} > gpurun_out/ev_${MODE}_summary.txt 2>&1
+tail -3 gpurun_out/ev_${MODE}_summary.txt

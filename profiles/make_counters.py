@@ -5,7 +5,7 @@ Collection (on the GPU box; counters in their own runs, kernel trace only; the p
 
     cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE"
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${MODE}_stats -o p -- $B
-    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 \   # (_F16 for the f16 modes)
               --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_mfma -o p -- $B
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_fetch -o p -- $B
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_write -o p -- $B
@@ -103,7 +103,7 @@ def main():
         total_ns += d["t1"] - d["t0"]
         f["busy"] += d["c"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         f["gui"] += d["c"].get("GRBM_GUI_ACTIVE", 0.0)
-        f["mops"] += d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+        f["mops"] += sum(d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_" + t, 0.0) for t in ("F32", "BF16", "F16"))
     conv = {}
     for src, key, cnt in ((fetch, "fetch", "nf"), (write, "write", "nw")):
         name = "FETCH_SIZE" if key == "fetch" else "WRITE_SIZE"

@@ -77,10 +77,11 @@ def _run_oracle(gp, dps, ep, data, f, cap):
     return out
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3"])
 def test_metric_config_step_vs_oracle(mode):
     """mode: the two fp32-grade arithmetic modes of the conv engine -- exact fp32 products on v_mfma_f32_32x32x2_f32, and
-    three bf16 planes / six v_mfma_f32_32x32x16_bf16 per product (24 mantissa bits) on the patch-resident kernels."""
+    three bf16 planes / six v_mfma_f32_32x32x16_bf16 per product (24 mantissa bits) on the patch-resident kernels, and two
+    fp16 planes of the range-scaled operands / three v_mfma_f32_32x32x16_f16 per product (22 mantissa bits)."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     HF = importlib.import_module("attention-gan_amd.backend.functional")

@@ -48,6 +48,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_BF16) == 18 * 1 * 32 * 32
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_F16) == 18 * 1 * 32 * 32
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 40, 4, 4, L.PREC_BF16X6) == 2 * 4 * 4 * 2 * 3 * 32 * 32   # 2 chunks x 4 phases x 4 taps
+    assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, L.PREC_F16X3) == 18 * 2 * 32 * 32  # fp16 hi/lo planes
     assert lib.agan_packed_weight_bytes(L.PACK_FWD, 3, 32, 3, 3, 9) == 0                           # unknown mode
     # effective precision: the patch kernels take 3x3 / 2x2-per-class / 4x4-s2 geometries with > 4 output channels
     g3 = L.ConvGeom()
@@ -58,7 +59,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.agan_conv_effective_prec(g3, L.PREC_BF16X6) == L.PREC_F32                         # RGB head: vector-ALU kernels
     g3.Cout, g3.R, g3.S, g3.OY[0], g3.OY[1] = 24, 1, 1, 0, 0
     assert lib.agan_conv_effective_prec(g3, L.PREC_F16) == L.PREC_F32                            # 1x1 / linear: fp32 MFMA
-    rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, 0, None, None, 0, None)
+    rc = lib.agan_conv_gather(None, None, None, None, g, None, 0, 0, None, None, 0, None, None, None)
     assert rc == -1 and b"conv" in lib.agan_last_error()
 
 
