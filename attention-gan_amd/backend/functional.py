@@ -484,10 +484,8 @@ class _ConvFn(Function):
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         pe_d = effective_precision(gd) if ctx.needs_input_grad[0] else L.PREC_F32
-        # weight gradient: the mode that is set, except that the scaled fp16 split exists only on the patch kernels' geometries
-        pe_w = _PRECISION[0]
-        if pe_w == L.PREC_F16X3 and effective_precision(gf) != L.PREC_F16X3:
-            pe_w = L.PREC_F32
+        # weight gradient: the mode the library will run it in (the fp16 split needs its operands' amax slots only then)
+        pe_w = L.load().agan_conv_wgrad_effective_prec(byref(gf), pf, _PRECISION[0]) if _PRECISION[0] != L.PREC_F32 else L.PREC_F32
         scaled_w = want_w and pe_w == L.PREC_F16X3
         dys = amax_of(dy) if (pe_d == L.PREC_F16X3 or scaled_w) else None      # ONE slot of dy serves both gradients
         side = None

@@ -839,6 +839,21 @@ int agan_conv_effective_prec(const agan_conv_geom* g, int prec) {
     return patch_supported(make_geom(g)) ? prec : AGAN_PREC_F32;
 }
 
+// the mode a weight gradient of forward geometry g runs in.  Besides the geometries the patch kernels do not take:
+//   * AGAN_PREC_BF16X6 -- fp32-grade by definition, so it may use whichever fp32-grade kernel is faster: the fp32 MFMA kernel
+//     (6.5 vs 10 ms per step at the metric config; -DAGAN_BF16X6_PATCH_WGRAD=1 builds the six-product patch kernel in);
+//   * the folded upsample conv (4 classes of 2x2 taps): its patch weight gradient is slower than the fp32 kernel in EVERY mode
+//     (0.61 / 0.52 vs 0.49 ms at 64x128 -> 64x256; 16 short reductions per tile) -- fp32 products are at least as accurate.
+int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int prec) {
+    if (prec == AGAN_PREC_F32 || check_geom(g) || prec_planes(prec) == 0) return AGAN_PREC_F32;
+    if (!patch_supported(make_geom(g))) return AGAN_PREC_F32;
+#ifndef AGAN_BF16X6_PATCH_WGRAD
+    if (prec == AGAN_PREC_BF16X6) return AGAN_PREC_F32;
+#endif
+    if (pack_mode == AGAN_PACK_UP_FWD) return AGAN_PREC_F32;
+    return prec;
+}
+
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (check_geom(g)) return 0;
     const Geom gg = make_geom(g);
@@ -948,14 +963,7 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
-    // geometries the patch kernels do not take run on the fp32 MFMA kernels (the operands are fp32 activations either way).
-    // AGAN_PREC_BF16X6 is fp32-grade by definition, so its weight gradients may use whichever fp32-grade kernel is faster:
-    // today that is the fp32 MFMA kernel (measured at the metric config: 6.5 vs 10 ms per step; build with
-    // -DAGAN_BF16X6_PATCH_WGRAD=1 to run the six-product patch kernel instead).
-    if (prec != AGAN_PREC_F32 && !patch_supported(make_geom(gg))) prec = AGAN_PREC_F32;
-#ifndef AGAN_BF16X6_PATCH_WGRAD
-    if (prec == AGAN_PREC_BF16X6) prec = AGAN_PREC_F32;
-#endif
+    prec = agan_conv_wgrad_effective_prec(gg, pack_mode, prec);     // (callers may pass the mode that is set: fp32 operands either way)
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
     const bool up = pack_mode == AGAN_PACK_UP_FWD;

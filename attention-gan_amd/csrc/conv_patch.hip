@@ -625,6 +625,25 @@ __device__ __forceinline__ u32x4 ds_read_tr8(const unsigned char* lds, unsigned 
     return r;
 }
 
+// ---- staging loads of the weight-gradient kernel: straight into ACCUMULATOR registers ----------------------------------------
+// The kernel holds 72-104 staged dwords per lane across its k loop next to the fragment double buffers; left to the register
+// allocator they start in arch VGPRs and are copied to AGPRs to make room (v_accvgpr_write needs the DATA, so every load was waited
+// for right after issue and nothing overlapped the k loop: ablation, round 2).  gfx90a+ VMEM can write AGPRs directly: the loads
+// are issued by inline asm with an "a" destination; the compiler does not track them, so consumers go through staged_wait().
+__device__ __forceinline__ u32x4 make_rsrc4(const void* p, size_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, (unsigned)bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ float buf_load_acc(u32x4 rsrc, unsigned voff, unsigned soff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=a"(v) : "v"(voff), "s"(rsrc), "s"(soff));
+    return v;
+}
+__device__ __forceinline__ void staged_wait(float (&v)[8]) {       // all staged loads have landed; ties the 8 values to the wait
+    asm volatile("s_waitcnt vmcnt(0)" : "+a"(v[0]), "+a"(v[1]), "+a"(v[2]), "+a"(v[3]), "+a"(v[4]), "+a"(v[5]), "+a"(v[6]), "+a"(v[7]));
+}
+
 template <int BJ> struct WgCfg {
     static constexpr int kYRow = BJ == 128 ? 336 : 144;       // bytes per pixel of the dy image (BJ x 16 bit + pad; odd multiple of 16 mod 256)
     static constexpr int kYPlane = 128 * kYRow;
@@ -671,8 +690,8 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
     const int twl = pp.twl, thl = pp.thl;
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const u32x4 rx = make_rsrc4(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const u32x4 rdy = make_rsrc4(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
     const int tile_beg = split * tiles_per_split, tile_end = min(pp.mtiles, tile_beg + tiles_per_split);
 
     // ---- staging items (tile independent parts) ----
@@ -691,34 +710,48 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
     }
     float xr[kItems][8], yr[C::kYItems][8];
 
-    auto load_tile = [&](int mt) {
+    // A wave can have 63 loads outstanding (vmcnt is 6 bits).  The 72-104 dword loads of a tile are therefore issued in TWO bursts:
+    // part 0 (the x patch and the first two dy items, 56 loads) before the k loop, part 1 (the rest of dy) in the middle of it, when
+    // part 0 has landed.  Issued as ONE burst the wave stalls at the 63rd load for a full memory latency, and with one workgroup per
+    // CU nothing else runs meanwhile (ablation, round 2: half of the kernel's time).  part -1 = everything (prologue).
+    auto load_tile = [&](int mt, int part) {
         const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
         const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+        if (part <= 0) {
 #pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            const int b = tb0 + xi_b[i];
-            const int iy = pp.IS * (ty0 + xi_j[i]) + by, ix = pp.IS * (tx0 + xi_i[i]) + bx;
-            const bool ok = (xi_oct[i] < kCH / 8) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-            const unsigned voff = ok ? (unsigned)((b * g.Cin + c0 + xi_oct[i] * 8) * ihw + iy * g.IW + ix) * 4u : kOOB;
-            const int nrem = g.Cin - c0 - xi_oct[i] * 8;
+            for (int i = 0; i < kItems; ++i) {
+                const int b = tb0 + xi_b[i];
+                const int iy = pp.IS * (ty0 + xi_j[i]) + by, ix = pp.IS * (tx0 + xi_i[i]) + bx;
+                const bool ok = (xi_oct[i] < kCH / 8) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                const unsigned voff = ok ? (unsigned)((b * g.Cin + c0 + xi_oct[i] * 8) * ihw + iy * g.IW + ix) * 4u : kOOB;
+                const int nrem = g.Cin - c0 - xi_oct[i] * 8;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xr[i][c] = buf_load_s(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+                for (int c = 0; c < 8; ++c) xr[i][c] = buf_load_acc(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+            }
         }
+        constexpr int kYFirst = 2;                      // dy items that ride with part 0
 #pragma unroll
         for (int i = 0; i < C::kYItems; ++i) {
-            const int e = tid + i * 256;
-            const int l = e & 127, oct = e >> 7;
-            const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-            const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
-            const bool ok = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
-            const int n = j0 + oct * 8;
-            const unsigned voff = ok ? (unsigned)((b * g.Cout + n) * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kOOB;
-            const int nrem = g.Cout - n;
+            const bool mine = part < 0 || (part == 0 ? i < kYFirst : i >= kYFirst);
+            if (mine) {
+                const int e = tid + i * 256;
+                const int l = e & 127, oct = e >> 7;
+                const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+                const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+                const bool ok = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+                const int n = j0 + oct * 8;
+                const unsigned voff = ok ? (unsigned)((b * g.Cout + n) * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kOOB;
+                const int nrem = g.Cout - n;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) yr[i][c] = buf_load_s(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * 4u);
+                for (int c = 0; c < 8; ++c) yr[i][c] = buf_load_acc(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * 4u);
+            }
         }
     };
     auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) staged_wait(xr[i]);
+#pragma unroll
+        for (int i = 0; i < C::kYItems; ++i) staged_wait(yr[i]);
 #pragma unroll
         for (int i = 0; i < kItems; ++i) {
             if (xi_oct[i] < kCH / 8) {
@@ -767,50 +800,127 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (tile_beg < tile_end) {
-        load_tile(tile_beg);
+        load_tile(tile_beg, -1);
         store_tile();
         __syncthreads();
         const int TW = 1 << twl;
-        const int nsteps = 8;                                     // 128 pixels / 16
+        constexpr int nsteps = 8;                                 // 128 pixels / 16
+        // tap offsets of this wave in registers (pp lives in the kernarg segment: indexing it by a runtime tap is a scalar
+        // load + s_waitcnt lgkmcnt(0) -- which also drains the LDS queue -- per tap and k-step)
+        constexpr bool kAllTaps = (TPW * WT == NT);               // every wave owns TPW valid taps (else the last wave's tail is masked)
+        unsigned toff[TPW];
+        bool tok[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tap = wt * TPW + t;
+            tok[t] = kAllTaps || tap < NT;
+            toff[t] = (unsigned)pp.tapoff[tap < NT ? tap : NT - 1];
+        }
+        // 16 consecutive lattice points of the tile per k-step: l = 16*kk .. 16*kk+15  (a tile row holds 1, 2, 4 ... of them; tiles
+        // narrower than 16 wrap into the next row / image, which the position arithmetic follows per 4-pixel block: a block never
+        // straddles a tile row, rows are >= 4 wide)
+        unsigned xc_tile = xcol;
+        auto xpos = [&](int kk, unsigned (&xo)[2]) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int l = kk * 16 + lpix + 4 * e;
+                const int tx = l & (TW - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+                xo[e] = xc_tile + (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes);
+            }
+        };
+        auto read_a = [&](int kk, u32x4 (&a)[NPL]) {
+            const unsigned yo = ylane + (unsigned)(kk * 16 * C::kYRow);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) a[p] = ds_read_tr8(ys + p * C::kYPlane, yo, yo + 4 * C::kYRow);
+        };
+        auto read_b = [&](const unsigned (&xo)[2], int t, u32x4 (&bb)[NPL]) {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) bb[p] = ds_read_tr8(xs + p * kPlaneBytes, xo[0] + toff[t], xo[1] + toff[t]);
+        };
+#ifdef AGAN_WG_TIMING
+        long long tph[6] = {0, 0, 0, 0, 0, 0};
+#define AGAN_TICK(k) do { const long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define AGAN_TICK(k) do { } while (0)
+#endif
         for (int mt = tile_beg; mt < tile_end; ++mt) {
+#ifdef AGAN_WG_TIMING
+            long long tlast = clock64();
+#endif
             const bool more = mt + 1 < tile_end;
-            if (more) load_tile(mt + 1);
+#if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 1
+            if (more) load_tile(mt + 1, 0);
+#endif
+            AGAN_TICK(0);
+            // (opaque per tile: otherwise all 8 x TPW x 2 fragment addresses of the unrolled loop are hoisted out of the tile loop and
+            //  held in VGPRs next to the 72-104 staging registers -- recomputing them costs a few dozen VALU adds per tile)
+            asm volatile("" : "+v"(xc_tile));
+            // software pipeline over (k-step, group of G taps) items, fully unrolled: the fragments of item i+1 are read while the
+            // MFMAs of item i run -- with ONE wave per SIMD (LDS: one workgroup per CU) nothing else hides the ~130-cycle LDS
+            // latency, and read-then-wait per tap left the matrix core idle two thirds of the loop (round-2 PMC: 17 % MFMA-busy).
+            // Both fragment sets are live at once (distinct registers by construction); sched_group_barrier interleaves the reads
+            // of the next item with the MFMAs of this one, tap by tap.
+            constexpr int G = (NPL == 1 || TPW <= 5) ? TPW : 3, NG = TPW / G;
+            static_assert(TPW % G == 0, "tap groups must tile the taps of a wave");
+            constexpr int kProd = NPL == 1 ? 1 : (NPL == 2 ? 3 : 6);
+            u32x4 a[2][NPL], bf[2][G][NPL];
+            unsigned xo[2][2];
+            xpos(0, xo[0]);
+            read_a(0, a[0]);
+#pragma unroll
+            for (int q = 0; q < G; ++q) read_b(xo[0], q, bf[0][q]);
+#if defined(AGAN_WG_ABLATE) && AGAN_WG_ABLATE == 3
+            if (mt == tile_beg)
+#endif
+#pragma unroll
             for (int kk = 0; kk < nsteps; ++kk) {
-                // 16 consecutive lattice points of the tile: l = 16*kk .. 16*kk+15  (a tile row holds 1, 2, 4 ... of them; tiles
-                // narrower than 16 wrap into the next row / image, which the position arithmetic below follows per 4-pixel block)
-                const int l0 = kk * 16;
-                u32x4 a[NPL];
-                {
-                    const unsigned yo = ylane + (unsigned)(l0 * C::kYRow);
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p) a[p] = ds_read_tr8(ys + p * C::kYPlane, yo, yo + 4 * C::kYRow);
-                }
-                // patch positions of this lane's two 4-pixel blocks (a block never straddles a tile row: rows are >= 4 wide)
-                unsigned xo[2];
+                for (int tg = 0; tg < NG; ++tg) {
+#if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 1
+                    if (kk == nsteps / 2 && tg == 0 && more) load_tile(mt + 1, 1);
+#endif
+                    const int cur = (kk * NG + tg) & 1, nxt = cur ^ 1;
+                    const bool last = (kk + 1 == nsteps) && (tg + 1 == NG);
+                    const bool newk = (tg + 1 == NG);                         // the next item starts the next k-step
+                    if (!last) {
+                        if (newk) {
+                            xpos(kk + 1, xo[(kk + 1) & 1]);
+                            read_a(kk + 1, a[(kk + 1) & 1]);
+                        }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int l = l0 + lpix + 4 * e;
-                    const int tx = l & (TW - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-                    xo[e] = xcol + (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes);
-                }
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    const int tap = wt * TPW + t;
-                    if (tap < NT) {
-                        u32x4 b[NPL];
-#pragma unroll
-                        for (int p = 0; p < NPL; ++p)
-                            b[p] = ds_read_tr8(xs + p * kPlaneBytes, xo[0] + (unsigned)pp.tapoff[tap], xo[1] + (unsigned)pp.tapoff[tap]);
-                        acc[t] = mfma_split<ET, NPL>(a, b, acc[t]);
+                        for (int q = 0; q < G; ++q) read_b(xo[newk ? (kk + 1) & 1 : kk & 1], (newk ? 0 : (tg + 1) * G) + q, bf[nxt][q]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);      // the reads above stay ABOVE this item's MFMAs (the scheduler sinks LDS loads to their use)
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (kAllTaps || tok[tg * G + q]) acc[tg * G + q] = mfma_split<ET, NPL>(a[kk & 1], bf[cur][q], acc[tg * G + q]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            AGAN_TICK(1);
             __syncthreads();
+            AGAN_TICK(2);
             if (more) {
+#ifdef AGAN_WG_TIMING
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) staged_wait(xr[i]);
+#pragma unroll
+                for (int i = 0; i < C::kYItems; ++i) staged_wait(yr[i]);
+                AGAN_TICK(3);
+#endif
+#if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 2
                 store_tile();
+#endif
+                AGAN_TICK(4);
                 __syncthreads();
+                AGAN_TICK(5);
             }
         }
+#ifdef AGAN_WG_TIMING
+        if (blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 3 && tid == 64)
+            printf("wg timing (cycles over %d tiles): issue %lld kloop %lld bar1 %lld loadwait %lld convert+store %lld bar2 %lld\n", tile_end - tile_beg,
+                   tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
     }
 
     // ---- D[cout][channel of the chunk] per tap -> dst[split][cls][cout][kprime], kprime = ((chunk*NPH + ph)*NT + tap)*32 + ci ----
@@ -1074,6 +1184,9 @@ int prec_planes(int prec) {
 // Can the patch kernels run this geometry?  (taps 2x2 / 3x3 per phase, images of at least 4x4 lattice points, tensors < 2^30)
 bool patch_supported(const Geom& g) {
     if (g.Cout <= 4) return false;                                    // <= 4 output channels: the vector-ALU kernels (conv_small.hip)
+    // <= 4 gathered channels (the image-input convs, the data gradient of the RGB heads): a stage would stage 3 of its 16-32
+    // channel slots; measured 2.5-7x slower than the fp32 k-table kernels (profiles/r02_*_conv_layer_table.txt, round 2)
+    if (g.Cin <= 4) return false;
     if (g.SY == 1) {
         if (!((g.R == 3 && g.S == 3) || (g.R == 2 && g.S == 2))) return false;
         if (g.DY != 1 && g.DY != -1) return false;

@@ -221,7 +221,7 @@ def cpu_baseline(batch, repeats=3):
 
 def side_measurements(args, dev, HF, LIB, step, words, sent, reals, n=8):
     """Short eager measurements reported BESIDE the headline, never inside it or its roofline:
-    random caption lengths 2..10 (the headline uses full-length captions), the other fp32-grade arithmetic mode, and the
+    random caption lengths 2..10 (the headline uses full-length captions), the other arithmetic modes of the conv engine, and the
     end-to-end step with the Inception-v3-shaped trunk (stock MIOpen convs, random weights) as the DAMSM image encoder and the
     bi-LSTM text encoder run on the device every step."""
     def rate(fn):
@@ -241,12 +241,14 @@ def side_measurements(args, dev, HF, LIB, step, words, sent, reals, n=8):
     lens_r = lens_r.to(dev)
     out["random_caption_lengths_2_10"] = rate(lambda: step.step(words, sent, lens_r, None, reals))
     lens_full = torch.full((B,), T, dtype=torch.int64, device=dev)
-    other = "f32" if args.precision != "f32" else "bf16x6"
-    HF.set_precision(LIB.PRECISIONS[other])
-    try:
-        out[f"precision_{other}"] = rate(lambda: step.step(words, sent, lens_full, None, reals))
-    finally:
-        HF.set_precision(LIB.PRECISIONS[args.precision])
+    for other in ("f32", "bf16x6", "f16x3", "bf16"):      # fp32-grade split modes (parity-tested at this size) and plain bf16
+        if other == args.precision:
+            continue
+        HF.set_precision(LIB.PRECISIONS[other])
+        try:
+            out[f"precision_{other}"] = rate(lambda: step.step(words, sent, lens_full, None, reals))
+        finally:
+            HF.set_precision(LIB.PRECISIONS[args.precision])
     try:
         RNN = importlib.import_module("attention-gan_amd.networks.rnn_encoder")
         step2 = build(dev, B, HF, "inception")

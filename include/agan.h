@@ -47,7 +47,7 @@ enum {
                              from an amax slot (see agan_absmax below), the weights are packed times 2^11                   */
 };
 /* The 16-bit modes run on the patch-resident kernels (csrc/conv_patch.hip), which take 3x3 / 2x2-per-class stride-1 and 4x4
- * stride-2 geometries with more than 4 output channels and images of at least 4x4; any other call (linear layers, the RGB
+ * stride-2 geometries with more than 4 input and output channels and images of at least 4x4; any other call (linear layers, the RGB
  * heads) runs in AGAN_PREC_F32 whatever mode is asked for.  agan_conv_effective_prec says which one a geometry gets -- pack the
  * weights for THAT precision (declared below, after agan_conv_geom). */
 
@@ -115,6 +115,9 @@ size_t agan_conv_ktable_elems(const agan_conv_geom* g);
 int agan_conv_ktable(const agan_conv_geom* g, int32_t* table, void* stream);
 
 int agan_conv_effective_prec(const agan_conv_geom* g, int prec);
+/* ... and the one its weight gradient gets (agan_conv_wgrad demotes by itself; a caller needs this to know whether the
+ * AGAN_PREC_F16X3 scales are wanted).  g = the FORWARD geometry, pack_mode = AGAN_PACK_FWD or AGAN_PACK_UP_FWD. */
+int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int prec);
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
 /* lrelu_mask (optional, data-gradient launches): a tensor of the OUTPUT's shape; out is multiplied by LeakyReLU'(mask) = 1 where
  * mask > 0, else 0.2 -- the backward of the LeakyReLU that produced this conv's forward input (the mask is that input), folded

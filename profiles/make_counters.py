@@ -38,6 +38,7 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel"]),
     ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel"]),
     ("weight packs", ["pack_"]),
+    ("absmax (f16x3: max|x| of small tensors)", ["absmax_kernel"]),
     ("bn_stats_partial", ["bn_stats_partial"]),
     ("bn_act_fwd (normalise + GLU/LeakyReLU)", ["bn_act_fwd_kernel"]),
     ("bn_bwd_partial", ["bn_bwd_partial"]),
