@@ -644,8 +644,16 @@ __device__ __forceinline__ void staged_wait(float (&v)[8]) {       // all staged
     asm volatile("s_waitcnt vmcnt(0)" : "+a"(v[0]), "+a"(v[1]), "+a"(v[2]), "+a"(v[3]), "+a"(v[4]), "+a"(v[5]), "+a"(v[6]), "+a"(v[7]));
 }
 
+// LDS row strides of the weight-gradient kernel.  ds_read_b64_tr_b16 serves 16 lanes per cycle: 4 consecutive pixels x 4 column groups
+// of 8 bytes, so the four pixel rows must start 8 banks wide windows that do not overlap: stride/4 mod 64 in {24, 72 = 8, 36}.  The
+// gather's 80-byte positions (20 banks: 0, 20, 40, 60 -> the last window wraps onto the first) and the first version's 336-byte dy rows
+// cost 39 % of the LDS cycles in bank conflicts (round-2 PMC); 96 / 288 / 144 bytes are conflict-free for these reads and for the
+// 8-lanes-per-cycle ds_write_b128 of the staging pass.
+constexpr int kWgPos = 96;
+constexpr int kWgPlane = kMaxPos * kWgPos;
+
 template <int BJ> struct WgCfg {
-    static constexpr int kYRow = BJ == 128 ? 336 : 144;       // bytes per pixel of the dy image (BJ x 16 bit + pad; odd multiple of 16 mod 256)
+    static constexpr int kYRow = BJ == 128 ? 288 : 144;       // bytes per pixel of the dy image (BJ x 16 bit + pad), see kWgPos
     static constexpr int kYPlane = 128 * kYRow;
     static constexpr int kYItems = 128 * (BJ / 8) / 256;      // (pixel, cout octet) staging items per thread
 };
@@ -667,9 +675,9 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
     constexpr int WJ = BJ / 32;                // waves along output channels
     constexpr int WT = 4 / WJ;                 // waves sharing the taps of a cout block
     constexpr int TPW = (NT + WT - 1) / WT;    // taps per wave
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * (kPlaneBytes + C::kYPlane)];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * (kWgPlane + C::kYPlane)];
     unsigned char* const xs = lds;
-    unsigned char* const ys = lds + NPL * kPlaneBytes;
+    unsigned char* const ys = lds + NPL * kWgPlane;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
         xi_i[i] = rem - xi_j[i] * pp.PW;
         xi_b[i] = pb;
         xi_oct[i] = oct;
-        xi_lds[i] = (unsigned)(p * kPosBytes + oct * 16);
+        xi_lds[i] = (unsigned)(p * kWgPos + oct * 16);
     }
     float xr[kItems][8], yr[C::kYItems][8];
 
@@ -765,7 +773,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
                     for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
                 }
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(xs + q * kPlaneBytes + xi_lds[i]) = v[q];
+                for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(xs + q * kWgPlane + xi_lds[i]) = v[q];
             }
         }
 #pragma unroll
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
         for (int t = 0; t < TPW; ++t) {
             const int tap = wt * TPW + t;
             tok[t] = kAllTaps || tap < NT;
-            toff[t] = (unsigned)pp.tapoff[tap < NT ? tap : NT - 1];
+            toff[t] = (unsigned)(pp.tappos[tap < NT ? tap : NT - 1] * kWgPos);
         }
         // 16 consecutive lattice points of the tile per k-step: l = 16*kk .. 16*kk+15  (a tile row holds 1, 2, 4 ... of them; tiles
         // narrower than 16 wrap into the next row / image, which the position arithmetic follows per 4-pixel block: a block never
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
             for (int e = 0; e < 2; ++e) {
                 const int l = kk * 16 + lpix + 4 * e;
                 const int tx = l & (TW - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-                xo[e] = xc_tile + (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes);
+                xo[e] = xc_tile + (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kWgPos);
             }
         };
         auto read_a = [&](int kk, u32x4 (&a)[NPL]) {
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
         };
         auto read_b = [&](const unsigned (&xo)[2], int t, u32x4 (&bb)[NPL]) {
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) bb[p] = ds_read_tr8(xs + p * kPlaneBytes, xo[0] + toff[t], xo[1] + toff[t]);
+            for (int p = 0; p < NPL; ++p) bb[p] = ds_read_tr8(xs + p * kWgPlane, xo[0] + toff[t], xo[1] + toff[t]);
         };
 #ifdef AGAN_WG_TIMING
         long long tph[6] = {0, 0, 0, 0, 0, 0};
