@@ -10,6 +10,7 @@ point-to-point (7 links x ~153 GB/s per GPU), so few large messages beat many sm
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -77,7 +78,10 @@ class GradBuckets:
         self._handles: List = []
         self._armed = False
         self.comm_stream: Optional[torch.cuda.Stream] = None
-        if self.world > 1:
+        # AGAN_DP_FORCE=1: run the whole exchange machinery (hooks, comm stream, async handles) in a world of ONE rank as well --
+        # the rehearsal of the `nccl` backend that a one-GPU box allows (RCCL refuses two ranks on one device)
+        self.active = self.world > 1 or (os.environ.get("AGAN_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+        if self.active:
             if opt.flat.is_cuda:
                 self.comm_stream = torch.cuda.Stream(device=opt.flat.device)
             for i, p in enumerate(opt.params):
@@ -113,7 +117,7 @@ class GradBuckets:
 
     def finish(self) -> float:
         """Join outstanding exchanges; returns the scale the optimiser must apply (1/world_size)."""
-        if self.world == 1:
+        if not self.active:
             return 1.0
         # buckets whose parameters received no gradient this backward (unused params) are reduced too so that
         # every rank issues the same collectives

@@ -284,7 +284,7 @@ class GanTrainStep(ModelTrainer):
         graph (graph-safe Philox state) unless static `noise` / `eps` buffers are given; BatchNorm counters and the Adam step
         counters live in device memory, so replays keep advancing exactly like eager steps.  The warm-up steps are real
         training steps.  Single-process only: with world_size > 1 run the eager `step()`."""
-        if self.g_buckets.world > 1:
+        if self.g_buckets.active:
             raise RuntimeError("capture(): the all-reduce path is not captured; use step() under torch.distributed")
         if not (isinstance(lengths, Tensor) and lengths.is_cuda and lengths.dtype == torch.int64):
             raise ValueError("capture(): lengths must be an int64 device tensor")

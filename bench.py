@@ -300,8 +300,11 @@ def main():
     backend = os.environ.get("AGAN_BENCH_BACKEND", "nccl")
     if os.environ.get("AGAN_BENCH_ONE_DEVICE") == "1":
         local = 0
-    if world > 1:
+    if world > 1 or os.environ.get("AGAN_DP_FORCE") == "1":        # (AGAN_DP_FORCE: one-rank rehearsal of the nccl path, dataparallel.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -312,6 +315,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
+    dp = dist.is_available() and dist.is_initialized()       # (world > 1, or the forced one-rank rehearsal)
 
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     LIB = importlib.import_module("attention-gan_amd.backend.lib")
@@ -344,9 +348,9 @@ def main():
         torch.cuda.synchronize()
         return t_host, (time.perf_counter() - t0) / n
 
-    use_graph = args.graph == "on"
+    use_graph = args.graph == "on" and not dp
     graphed = None
-    if world == 1 and args.graph == "auto":
+    if not dp and args.graph == "auto":
         for _ in range(2):
             eager_step()
         t_host, t_eager = probe(eager_step)
@@ -359,25 +363,25 @@ def main():
         else:
             print(f"[bench] eager: host enqueue {t_host * 1e3:.1f} ms of a {t_eager * 1e3:.2f} ms step -> eager (no graph capture)",
                   file=sys.stderr, flush=True)
-    elif world == 1 and args.graph == "on":
+    elif not dp and args.graph == "on":
         graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
     one_step = graphed.replay if use_graph else eager_step
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -443,7 +447,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -152,3 +152,47 @@ def test_two_rank_step_equals_mean_of_shard_gradients():
         for k, v in d.state_dict().items():
             if k.endswith((".weight", ".bias")):
                 close(got[0][2][i][k], v.cpu(), f"D{i} {k}")
+
+
+def _nccl_one_rank_worker(port, q):
+    """world of ONE rank on the `nccl` (= RCCL) backend with the exchange machinery forced on: hooks, three discriminator streams,
+    comm streams, async handles and the bucket joins run exactly as at N > 1; a SUM all-reduce over one rank is the identity."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AGAN_DP_FORCE="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        G, Ds, enc = _nets(dev)
+        step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=64 << 10)
+        assert step.g_buckets.active and len(step.g_buckets.bounds) > 1
+        words, sent, lens, reals, noise, eps = _shard(0, dev)
+        for _ in range(2):
+            out = step.step(words, sent, lens, None, reals, noise, eps)
+        torch.cuda.synchronize()
+        q.put(({k: v.detach().cpu().numpy() for k, v in G.state_dict().items()}, float(out["g_total"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_nccl_exchange_is_identity():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(free_port(), q))
+    p.start()
+    g_sd, g_total = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    # the same two steps without torch.distributed: bitwise the same weights (the exchange added nothing and reordered nothing)
+    dev = torch.device("cuda", 0)
+    G, Ds, enc = _nets(dev)
+    step = TR.GanTrainStep(G, Ds, enc)
+    words, sent, lens, reals, noise, eps = _shard(0, dev)
+    for _ in range(2):
+        out = step.step(words, sent, lens, None, reals, noise, eps)
+    torch.cuda.synchronize()
+    assert float(out["g_total"]) == g_total
+    for k, v in G.state_dict().items():
+        assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
