@@ -397,6 +397,33 @@ def test_hip_graph_replay_equals_eager_steps():
             assert torch.equal(va, vb), k
 
 
+def test_checkpoint_after_graph_replay_resumes_bitwise():
+    """A checkpoint taken after HIP-graph replays carries the DEVICE step counter (replays never touch the host one): a fresh
+    trainer that loads it and takes one eager step lands bit for bit where the uninterrupted run lands (Adam's bias corrections
+    depend on the step number)."""
+    import copy
+    G, Ds, enc, d = _setup(13)
+    a = TR.GanTrainStep(G, Ds, enc)
+    lens = torch.tensor(d["lens"], dtype=torch.int64, device=DEV)
+    g = a.capture(d["words"], d["sent"], lens, d["reals"], warmup=1, noise=d["noise"], eps=d["eps"])
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ckpt = copy.deepcopy(a.state_dict())
+    assert int(a.g_opt.step_state[0]) == 4 and float(ckpt["g_optim"]["state"][0]["step"]) == 4.0
+    out_a = a.step(d["words"], d["sent"], lens, None, d["reals"], d["noise"], d["eps"])
+    G2, Ds2, enc2, _ = _setup(98)
+    b = TR.GanTrainStep(G2, Ds2, enc2)
+    b.load_state_dict(ckpt)
+    out_b = b.step(d["words"], d["sent"], lens, None, d["reals"], d["noise"], d["eps"])
+    torch.cuda.synchronize()
+    for k in ("d_loss0", "d_loss1", "d_loss2", "g_total"):
+        assert float(out_a[k]) == float(out_b[k]), k
+    for ma, mb in zip([a.G] + a.Ds, [b.G] + b.Ds):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), k
+
+
 def test_side_stream_weight_gradients_match_inline():
     """overlap_weight_gradients forks every conv weight/bias gradient onto a side stream (joined by the optimiser step): two
     steps must land bit for bit where the inline path lands (a missed join would show as a stale or torn gradient)."""
