@@ -17,6 +17,12 @@ using namespace agan;
 #define AGAN_PRAGMA_(x) _Pragma(#x)
 #define AGAN_PRAGMA(x) AGAN_PRAGMA_(x)
 #define AGAN_PAIR_UNROLL AGAN_PRAGMA(unroll AGAN_PAIR_UNROLL_N)
+#ifndef AGAN_PAIR_MFMA_UNROLL
+#define AGAN_PAIR_MFMA_UNROLL 4
+#endif
+#ifndef AGAN_PAIR_MFMA_WAVES
+#define AGAN_PAIR_MFMA_WAVES 4
+#endif
 
 namespace {
 
@@ -165,6 +171,333 @@ __global__ __launch_bounds__(kNT) void words_pair_fwd_kernel(const float* __rest
     }
     if (i == j && threadIdx.x < S) {                                    // att_maps.append(attn[i]), :63
         for (int w = 0; w < L; ++w) maps[((size_t)i * T + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA variant of the pair kernels for the metric shapes: seq_len <= 12, nef a multiple of 16 up to 256, regions <= 292.
+//
+// The region x word contractions  scores[r][w] = sum_d f[d][r] e[d][w],  ctx[d][w] = sum_r f[d][r] a2[r][w]  and their three
+// backward counterparts run on v_mfma_f32_16x16x4_f32 (exact fp32 products): the 16-wide j axis holds the <= 12 words, the feature
+// operand comes straight from global memory (NCHW rows for a region-indexed result, the transposed copy for a channel-indexed
+// one: either way a lane group reads 64 consecutive bytes) and the [.][word] operand from LDS.  Why MFMA although fp32 MFMA is only
+// twice the vector ALU rate: in the thread-per-row form every thread re-reads the shared 12-float row (3 ds_read_b128 per 12 FMAs) and
+// the five waves of a pair saturate the LDS pipe (round-2 analysis: ~190 K LDS cycles per pair); a 16x16x4 tile reads that row once
+// per 16 rows.  12-float rows put lane (i, k) of an operand read on bank 12 i + k: all 64 banks, conflict-free.
+// Reductions stay in a fixed order (k ascending inside a tile, tiles independent): bit-reproducible like the vector form.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMW = 12;        // LDS row width (words)
+constexpr int kMD = 256;       // channel rows
+constexpr int kMS = 292;       // region rows: 17 * 17 = 289 padded to a multiple of 4 (the k axis of the channel-indexed contractions)
+
+template <bool BWD>
+struct PairMfmaSmem {
+    alignas(16) float e[kMD][kMW];      // caption words   e[d][w]  (0 for w >= L)
+    alignas(16) float c[kMD][kMW];      // weighted context c[d][w]; backward: d c, then the region part of d e
+    alignas(16) float a2[kMS][kMW];     // attention a2[r][w] (rows >= S zero)
+    alignas(16) float ds[BWD ? kMS : 1][kMW];   // backward: d a2 (scratch), then d(raw score) (rows >= S zero)
+    float num[kMW], n1[kMW], n2[kMW], cosv[kMW];
+    float colmax[kMW], colsum[kMW];
+    float dotw[kNT / 64][kMW];
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// Feature operand of a wave: FOUR 16-row tiles at once whose rows interleave -- tile q, row i <-> feature row base + 4 i + q -- so that
+// the A values of lane (i, k) for the four tiles are ONE aligned 16-byte load (a dword per tile and MFMA cost four times the cache-line
+// requests and made the first MFMA version 2.5x SLOWER than the vector kernels).
+//
+// out[r][w] = sum_d f[d][r] * bm[d][w]   (rows r < S written, columns < kMW); fjP = features [D][kMS], rows zero-padded and 16-B aligned;
+// wave v owns regions 64 v .. 64 v + 63
+__device__ __forceinline__ void mfma_region_rows(const float* __restrict__ fjP, const float (*bm)[kMW], float (*out)[kMW], int D, int S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mi = lane & 15, kq = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = min(wave * 64 + 4 * mi, kMS - 4);          // (regions beyond the padded row: clamped address, never stored)
+    const float* fp = fjP + (size_t)kq * kMS + col;
+AGAN_PRAGMA(unroll AGAN_PAIR_MFMA_UNROLL)
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        const float b = bm[d0 + kq][mi];                       // B[k = d][j = w]   (columns 12..15 read the next row: never stored)
+        const f32x4 a = *reinterpret_cast<const f32x4*>(fp + (size_t)d0 * kMS);      // A[i][k = d] of the four tiles
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma4(a[q], b, acc[q]);
+    }
+    if (mi < kMW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 64 + 4 * (4 * kq + r) + q;             // D[i = 4 (l >> 4) + r][j = l & 15] of tile q
+                if (row < S) out[row][mi] = acc[q][r];
+            }
+    }
+}
+
+// out[d][w] = sum_r f[d][r] * bm[r][w]  over the kMS padded regions (rows >= S of bm are zero); fjT = features as [S][D];
+// wave v < D / 64 owns channels 64 v .. 64 v + 63
+__device__ __forceinline__ void mfma_channel_rows(const float* __restrict__ fjT, const float (*bm)[kMW], float (*out)[kMW], int D, int S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mi = lane & 15, kq = lane >> 4;
+    if (wave * 64 >= D) return;                                  // (wave-uniform; no barrier inside)
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ft = fjT + wave * 64 + 4 * mi;
+AGAN_PRAGMA(unroll AGAN_PAIR_MFMA_UNROLL)
+    for (int r0 = 0; r0 < kMS; r0 += 4) {
+        const float b = bm[r0 + kq][mi];                        // B[k = r][j = w]
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ft + (size_t)min(r0 + kq, S - 1) * D);   // A[i][k = r] of the four tiles
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma4(a[q], b, acc[q]);
+    }
+    if (mi < kMW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[wave * 64 + 4 * (4 * kq + r) + q][mi] = acc[q][r];
+    }
+}
+
+// Forward of a pair (same contract as pair_forward): on return sm.e, sm.a2, sm.c, sm.cosv/num/n1/n2 are valid, a1[] is thread r's
+// first-softmax row (valid for r < S).
+template <bool BWD>
+__device__ __forceinline__ void pair_forward_mfma(PairMfmaSmem<BWD>& sm, const float* __restrict__ fjP, const float* __restrict__ fjT,
+                                                  const float* __restrict__ ei, int D, int T, int S, int L, float scale, float gamma1,
+                                                  float eps, float (&a1)[kMW]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < D * kMW; i += kNT) {
+        const int d = i / kMW, w = i - d * kMW;
+        sm.e[d][w] = w < L ? ei[(size_t)d * T + w] : 0.f;
+    }
+    __syncthreads();
+    mfma_region_rows(fjP, sm.e, sm.a2, D, S);                   // raw scores (attention.py:99)
+    __syncthreads();
+    const int r = tid;
+    const bool rlive = r < S;
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) a1[w] = 0.f;
+    if (rlive) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            a1[w] = w < L ? sm.a2[r][w] * scale : -INFINITY;
+            mx = fmaxf(mx, a1[w]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            a1[w] = __expf(a1[w] - mx);
+            sum += a1[w];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            a1[w] *= inv;
+            sm.a2[r][w] = a1[w] * gamma1;
+        }
+    } else if (r < kMS) {
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) sm.a2[r][w] = 0.f;        // the padded tail of the k axis
+    }
+    __syncthreads();
+    for (int w = wave; w < L; w += kNT / 64) {                  // softmax over regions, one word column per wave (attention.py:112)
+        float mx = -INFINITY;
+        for (int q = lane; q < S; q += 64) mx = fmaxf(mx, sm.a2[q][w]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int q = lane; q < S; q += 64) s += __expf(sm.a2[q][w] - mx);
+        s = wave_sum(s);
+        if (lane == 0) { sm.colmax[w] = mx; sm.colsum[w] = s; }
+    }
+    __syncthreads();
+    if (rlive) {
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) sm.a2[r][w] = w < L ? __expf(sm.a2[r][w] - sm.colmax[w]) / sm.colsum[w] : 0.f;
+    }
+    __syncthreads();
+    mfma_channel_rows(fjT, sm.a2, sm.c, D, S);                  // weighted context (attention.py:119)
+    __syncthreads();
+    for (int w = wave; w < L; w += kNT / 64) {                  // cosine per word (words_loss.py:20-27,72)
+        float nu = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float ev = sm.e[d][w], cv = sm.c[d][w];
+            nu += ev * cv; s1 += ev * ev; s2 += cv * cv;
+        }
+        nu = wave_sum(nu); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            const float a = sqrtf(s1), b = sqrtf(s2);
+            sm.num[w] = nu; sm.n1[w] = a; sm.n2[w] = b;
+            sm.cosv[w] = nu / fmaxf(a * b, eps);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kNT) void words_pair_fwd_mfma_kernel(const float* __restrict__ feat, const float* __restrict__ featT,
+                                                                  const float* __restrict__ wemb, const int64_t* __restrict__ lens,
+                                                                  float gamma1, float gamma2, float gamma3, float* __restrict__ sim,
+                                                                  float* __restrict__ maps, int B, int D, int T, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairMfmaSmem<false>& sm = *reinterpret_cast<PairMfmaSmem<false>*>(smem_raw);
+    const int j = blockIdx.x, i = blockIdx.y;      // image j, caption i
+    const int L = min((int)lens[i], T);
+    float a1[kMW];
+    const float* featP = featT + (size_t)B * D * S;                 // the padded copy follows the transposed one in the workspace
+    pair_forward_mfma<false>(sm, featP + (size_t)j * D * kMS, featT + (size_t)j * D * S, wemb + (size_t)i * D * T, D, T, S, L,
+                             rsqrtf((float)D), gamma1, 1e-8f, a1);
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w]);     // words_loss.py:77-79
+        sim[(size_t)j * B + i] = logf(s) * gamma3;                      // :93
+    }
+    if (i == j && threadIdx.x < S) {                                    // att_maps.append(attn[i]), :63
+        for (int w = 0; w < L; ++w) maps[((size_t)i * T + w) * S + threadIdx.x] = sm.a2[threadIdx.x][w];
+    }
+}
+
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(AGAN_PAIR_MFMA_WAVES))) void words_pair_bwd_mfma_kernel(
+    const float* __restrict__ feat, const float* __restrict__ featT, const float* __restrict__ wemb, const int64_t* __restrict__ lens,
+    const float* __restrict__ dS, const float* __restrict__ dloss, float gamma1, float gamma2, float gamma3, float* __restrict__ part_f,
+    float* __restrict__ part_w, int B, int D, int T, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PairMfmaSmem<true>& sm = *reinterpret_cast<PairMfmaSmem<true>*>(smem_raw);
+    const int j = blockIdx.x, i = blockIdx.y;
+    const float g = dS[(size_t)j * B + i] * dloss[0] * gamma3;     // d loss / d log-sum-exp of this pair
+    float* pf = part_f + ((size_t)j * B + i) * D * S;
+    float* pw = part_w + ((size_t)i * B + j) * D * T;
+    if (g == 0.f) {                                                // masked pair (uniform across the workgroup): zero slabs
+        for (int e = threadIdx.x; e < D * S; e += kNT) pf[e] = 0.f;
+        for (int e = threadIdx.x; e < D * T; e += kNT) pw[e] = 0.f;
+        return;
+    }
+    const int L = min((int)lens[i], T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mi = lane & 15, kq = lane >> 4;
+    const float scale = rsqrtf((float)D), eps = 1e-8f;
+    const float* fjP = featT + (size_t)B * D * S + (size_t)j * D * kMS;      // padded [D][kMS] copy (after the transposed one)
+    const float* fjT = featT + (size_t)j * D * S;
+    float a1[kMW];
+    pair_forward_mfma<true>(sm, fjP, fjT, wemb + (size_t)i * D * T, D, T, S, L, scale, gamma1, eps, a1);
+
+    // --- d cos, then d num / d n1 / d n2 per word (uniform, recomputed by every thread from LDS) ---
+    float dnum[kMW], dn1[kMW], dn2[kMW];
+    {
+        float mx = -INFINITY;
+        for (int w = 0; w < L; ++w) mx = fmaxf(mx, gamma2 * sm.cosv[w]);
+        float s = 0.f;
+        for (int w = 0; w < L; ++w) s += expf(gamma2 * sm.cosv[w] - mx);
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            dnum[w] = dn1[w] = dn2[w] = 0.f;
+            if (w < L) {
+                const float dcos = g * gamma2 * expf(gamma2 * sm.cosv[w] - mx) / s;
+                const float nn = sm.n1[w] * sm.n2[w];
+                if (nn > eps) {
+                    dnum[w] = dcos / nn;
+                    const float k = -dcos * sm.num[w] / (nn * nn);
+                    dn1[w] = k * sm.n2[w];
+                    dn2[w] = k * sm.n1[w];
+                } else {
+                    dnum[w] = dcos / eps;      // clamp(min=eps) active: denominator is a constant
+                }
+            }
+        }
+    }
+    // --- thread d: de (direct part) in registers, dc overwrites c in LDS ---
+    float de[kMW];
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) de[w] = 0.f;
+    if (tid < D) {
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            const float ev = sm.e[tid][w], cv = sm.c[tid][w];
+            de[w] = dnum[w] * cv + (sm.n1[w] > 0.f ? dn1[w] * ev / sm.n1[w] : 0.f);
+            sm.c[tid][w] = dnum[w] * ev + (sm.n2[w] > 0.f ? dn2[w] * cv / sm.n2[w] : 0.f);
+        }
+    }
+    __syncthreads();
+    // --- da2[r][w] = sum_d f[d][r] dc[d][w]  (into the ds scratch) ---
+    mfma_region_rows(fjP, sm.c, sm.ds, D, S);
+    __syncthreads();
+    const int r = tid;
+    const bool rlive = r < S;
+    float a2r[kMW], da2[kMW];
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) {
+        a2r[w] = rlive ? sm.a2[r][w] : 0.f;
+        da2[w] = rlive ? sm.ds[r][w] : 0.f;
+    }
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) {
+        const float v = wave_sum(a2r[w] * da2[w]);
+        if (lane == 0) sm.dotw[wave][w] = v;
+    }
+    __syncthreads();                 // (also: every thread has read its da2 row, the scratch may be overwritten)
+    float ds[kMW];
+    {
+        float inner = 0.f;
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) {
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < kNT / 64; ++q) dot += sm.dotw[q][w];          // fixed order over the five waves
+            ds[w] = gamma1 * a2r[w] * (da2[w] - (w < L ? dot : 0.f));         // softmax-over-regions backward = d a1[w]
+            inner += a1[w] * ds[w];
+        }
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) ds[w] = (w < L && rlive) ? a1[w] * (ds[w] - inner) * scale : 0.f;   // d raw score
+    }
+    if (r < kMS) {
+#pragma unroll
+        for (int w = 0; w < kMW; ++w) sm.ds[r][w] = ds[w];      // (zero for the padded rows)
+    }
+    __syncthreads();
+    // --- dfeat[j][d][r] = sum_w dc[d][w] a2[r][w] + e[d][w] ds[r][w]: 16 x 16 tiles, k = the 12 words of each term ---
+    {
+        const int nrt = (S + 15) >> 4, ndt = D >> 4;
+        float ba[4][3], bd[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = min((wave + 5 * q) * 16 + mi, kMS - 1);           // B[k = w][j = r]
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ba[q][t] = sm.a2[row][4 * t + kq];
+                bd[q][t] = sm.ds[row][4 * t + kq];
+            }
+        }
+        for (int dt = 0; dt < ndt; ++dt) {
+            float ac[3], ae[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ac[t] = sm.c[dt * 16 + mi][4 * t + kq];                       // A[i = d][k = w]
+                ae[t] = sm.e[dt * 16 + mi][4 * t + kq];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rt = wave + 5 * q;
+                if (rt < nrt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc = mfma4(ac[t], ba[q][t], acc);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc = mfma4(ae[t], bd[q][t], acc);
+                    const int rc = rt * 16 + mi;
+                    if (rc < S) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) pf[(size_t)(dt * 16 + 4 * kq + rr) * S + rc] = acc[rr];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                 // everyone is done reading dc: its storage takes the region part of d e
+    mfma_channel_rows(fjT, sm.ds, sm.c, D, S);
+    __syncthreads();
+    if (tid < D) {
+        float* dwi = pw + (size_t)tid * T;
+#pragma unroll
+        for (int w = 0; w < kMW; ++w)
+            if (w < T) dwi[w] = w < L ? de[w] + sm.c[tid][w] : 0.f;
     }
 }
 
@@ -356,7 +689,9 @@ AGAN_PAIR_UNROLL
 }
 
 // featT[b][s][d] = feat[b][d][s]: 32x32 tiles through LDS, both sides coalesced (7 MB at the metric shapes)
-__global__ __launch_bounds__(256) void feat_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int D, int S) {
+// outP (optional): the same features as [B][D][SP] with zero-padded, 16-byte aligned rows (the MFMA pair kernels' region operand)
+__global__ __launch_bounds__(256) void feat_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ outP,
+                                                             int D, int S, int SP) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, d0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -367,6 +702,11 @@ __global__ __launch_bounds__(256) void feat_transpose_kernel(const float* __rest
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (s0 + k < S && d0 + tx < D) dst[(size_t)(s0 + k) * D + d0 + tx] = tile[tx][k];
+    if (outP) {
+        float* dp = outP + (size_t)b * D * SP;
+        for (int k = ty; k < 32; k += 8)
+            if (d0 + k < D && s0 + tx < SP) dp[(size_t)(d0 + k) * SP + s0 + tx] = tile[k][tx];
+    }
 }
 
 // out[row][e] = sum_k part[row][k][e], k = 0..B-1 in order (row = image for dfeat, caption for dwemb)
@@ -546,6 +886,13 @@ __global__ __launch_bounds__(kNT) void func_attn_bwd_kernel(const float* __restr
 template <int TMAX, int DR = kNT>
 constexpr size_t pair_smem_bytes() { return sizeof(PairSmem<TMAX, DR>); }
 
+// shapes the MFMA pair kernels take (everything else runs the thread-per-row kernels); AGAN_PAIR_VALU=1 in the environment forces
+// the latter (A/B measurements)
+inline bool pair_mfma_ok(int D, int T, int S) {
+    static const bool off = [] { const char* v = getenv("AGAN_PAIR_VALU"); return v && v[0] == '1'; }();
+    return !off && T <= kMW && D <= kMD && (D & 63) == 0 && S <= kMS - 3 && S >= 16;
+}
+
 // the [B][B] + 2[B] matrix of the contrastive kernel exceeds the default 64 KB dynamic-LDS limit at B >= 127 (kMaxB = 128)
 inline void allow_ce_smem() {      // (once per process: one process drives one GPU)
     static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(contrastive_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -557,7 +904,9 @@ inline void allow_ce_smem() {      // (once per process: one process drives one 
 
 extern "C" {
 
-size_t agan_words_loss_save_elems(int B, int D, int T, int S) { return (size_t)B * B + (size_t)B * D * S; }   // dS, transposed features
+size_t agan_words_loss_save_elems(int B, int D, int T, int S) {      // dS, transposed features, zero-padded features
+    return (size_t)B * B + (size_t)B * D * S + (pair_mfma_ok(D, T, S) ? (size_t)B * D * kMS : 0);
+}
 
 int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, float gamma1,
                         float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps, float* save, int B,
@@ -569,7 +918,8 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     hipStream_t st = as_stream(stream);
     dim3 grid(B, B);
     float* featT = save + (size_t)B * B;              // [B][S][D], kept for the backward
-    hipLaunchKernelGGL(feat_transpose_kernel, dim3(cdiv(S, 32), cdiv(D, 32), B), dim3(256), 0, st, feat, featT, D, S);
+    float* featP = pair_mfma_ok(D, T, S) ? featT + (size_t)B * D * S : nullptr;
+    hipLaunchKernelGGL(feat_transpose_kernel, dim3(cdiv(featP ? kMS : S, 32), cdiv(D, 32), B), dim3(256), 0, st, feat, featT, featP, D, S, kMS);
 #define AGAN_PAIR_FWD(TM, DRR)                                                                                                          \
     do {                                                                                                                               \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_kernel<TM, DRR>),             \
@@ -579,7 +929,13 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
         hipLaunchKernelGGL((words_pair_fwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, featT, wemb, lens, gamma1,  \
                            gamma2, gamma3, sim, attn_maps, B, D, T, S);                                                                \
     } while (0)
-    if (T <= 12 && D <= 256) AGAN_PAIR_FWD(12, 256);
+    if (pair_mfma_ok(D, T, S)) {
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_fwd_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairMfmaSmem<false>));
+        (void)attr_;
+        hipLaunchKernelGGL(words_pair_fwd_mfma_kernel, grid, dim3(kNT), sizeof(PairMfmaSmem<false>), st, feat, featT, wemb, lens, gamma1, gamma2,
+                           gamma3, sim, attn_maps, B, D, T, S);
+    } else if (T <= 12 && D <= 256) AGAN_PAIR_FWD(12, 256);
     else if (T <= 16) AGAN_PAIR_FWD(16, kNT);
     else AGAN_PAIR_FWD(32, kNT);
 #undef AGAN_PAIR_FWD
@@ -615,7 +971,13 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
         hipLaunchKernelGGL((words_pair_bwd_kernel<TM, DRR>), grid, dim3(kNT), smem_, st, feat, save + (size_t)B * B, wemb, lens, save,   \
                            dloss, gamma1, gamma2, gamma3, part_f, part_w, B, D, T, S);                                                 \
     } while (0)
-    if (T <= 12 && D <= 256) AGAN_PAIR_BWD(12, 256);
+    if (pair_mfma_ok(D, T, S)) {
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(words_pair_bwd_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairMfmaSmem<true>));
+        (void)attr_;
+        hipLaunchKernelGGL(words_pair_bwd_mfma_kernel, grid, dim3(kNT), sizeof(PairMfmaSmem<true>), st, feat, save + (size_t)B * B, wemb, lens,
+                           save, dloss, gamma1, gamma2, gamma3, part_f, part_w, B, D, T, S);
+    } else if (T <= 12 && D <= 256) AGAN_PAIR_BWD(12, 256);
     else if (T <= 16) AGAN_PAIR_BWD(16, kNT);
     else AGAN_PAIR_BWD(32, kNT);
 #undef AGAN_PAIR_BWD
