@@ -5,7 +5,6 @@ from __future__ import annotations
 import contextlib
 import math
 import os
-from datetime import datetime
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -60,35 +59,10 @@ class ModelTrainer:
     def _denormalise_multiple(self, tensors: List[Tensor]) -> List[Tensor]:
         return [self._denormalise_single(t) for t in tensors]
 
-    def _plot_history(self, history, epoch=None, window_size=100, name='loss_hist', folder='generated_images') -> None:
-        import matplotlib
-        matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
-        for h in ([history] if not isinstance(history[0], list) else history):
-            avg = [sum(h[i:i + window_size]) / window_size for i in range(max(0, len(h) - window_size + 1))]
-            plt.plot(avg)
-        os.makedirs(folder, exist_ok=True)
-        plt.savefig(f"{folder}/epoch_{epoch}-{name}")
-        plt.close()
+    def _plot_history(self, *args, **kwargs) -> None:
+        raise NotImplementedError("plotting is outside the hot-path scope (SURVEY.md section 2 #7): use the reference's helpers on CPU")
 
-    def _plot_image_grid(self, fake_images: List[Tensor], epoch: int = None, folder='generated_images') -> None:
-        import matplotlib
-        matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
-        n = len(fake_images[0])
-        side = int(math.isqrt(n))
-        os.makedirs(folder, exist_ok=True)
-        for images in fake_images:
-            res = images.shape[-1]
-            imgs = images[:side * side].detach().cpu()
-            f, ax = plt.subplots(side, side, squeeze=False)
-            for k in range(side * side):
-                a = ax[k // side][k % side]
-                a.axis('off')
-                a.imshow(imgs[k].permute(1, 2, 0).clamp(0, 1))
-            stamp = str(datetime.now()).split('.')[0].replace(':', '-')
-            plt.savefig(f'{folder}/epoch_{epoch}-{res}x{res}.png' if epoch else f'{folder}/_{res}x{res}-{stamp}.png')
-            plt.close()
+    _plot_image_grid = _plot_history
 
     def _save_weights(self, modules: List, root_folder='saved_weights') -> None:
         """state_dict per module at {root}/{ClassName}.pkl.  Optimisers get an index suffix so that the reference's
