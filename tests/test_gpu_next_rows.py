@@ -397,6 +397,18 @@ def test_hip_graph_replay_equals_eager_steps():
             assert torch.equal(va, vb), k
 
 
+def test_hip_graph_replay_equals_eager_steps_f16x3():
+    """The same in the fp16 split mode: the amax arena (one zero-fill per step, slots handed out in call order) is captured with
+    the step, so a replay fills and reads the slots exactly like an eager step does."""
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    HF.set_precision(L.PREC_F16X3)
+    try:
+        test_hip_graph_replay_equals_eager_steps()
+    finally:
+        HF.set_precision(L.PREC_F32)
+
+
 def test_checkpoint_after_graph_replay_resumes_bitwise():
     """A checkpoint taken after HIP-graph replays carries the DEVICE step counter (replays never touch the host one): a fresh
     trainer that loads it and takes one eager step lands bit for bit where the uninterrupted run lands (Adam's bias corrections
