@@ -154,7 +154,9 @@ def build(dev, batch, HF, encoder="standin"):
     enc = (ENC.StandInImageEncoder(EMB) if encoder == "standin" else ENC.CNNEncoder(EMB)).to(dev)
     enc.freeze_all_weights()
     enc.eval()                     # the reference loads it with _load_weights(), which puts it in eval mode (trainer.py:124)
-    step = TR.GanTrainStep(G, Ds, enc)
+    # (AGAN_BUCKET_MB: gradient all-reduce bucket size for scaling experiments; default = the trainer's 64 MB)
+    mb = os.environ.get("AGAN_BUCKET_MB")
+    step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=int(mb) << 20) if mb else TR.GanTrainStep(G, Ds, enc)
     step.overlap_weight_gradients = os.environ.get("AGAN_WGRAD_SIDE_STREAM", "0") == "1"      # (A/B switch)
     return step
 
@@ -290,6 +292,12 @@ def main():
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented steps to this file")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON report of rank 0.  Libraries write there too (RCCL prints its version banner to
+    # stdout when a communicator is created, MIOpen its find-db notes): everything but the report goes to stderr.
+    sys.stdout.flush()
+    report_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -446,7 +454,8 @@ def main():
             line["variants"] = side_measurements(args, dev, HF, LIB, step, words, sent, reals)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(report_fd, (json.dumps(line) + "\n").encode())
     if dp:
         dist.destroy_process_group()
 
