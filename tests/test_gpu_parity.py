@@ -594,6 +594,29 @@ def test_words_loss_kernel_variants_vs_oracle(T_, D_):
     assert_close(wd.grad, wr.grad, RTOL, "dwemb")
 
 
+@pytest.mark.parametrize("D_,T_,side,dup", [(64, 12, 17, True), (128, 5, 8, False), (192, 10, 16, True), (256, 3, 5, False)])
+def test_words_loss_mfma_pair_kernels_vs_oracle(D_, T_, side, dup):
+    """the MFMA pair kernels (nef a multiple of 64 up to 256, seq_len <= 12, 16..289 regions) at their shape limits: fewer channel
+    waves than five, 12 words (no padding column), region counts that are not tile multiples, same-class masked pairs (zero slabs)"""
+    WL = importlib.import_module("attention-gan_amd.losses.words_loss").WordsLoss
+    gen = torch.Generator().manual_seed(D_ + T_ * 7 + side)
+    B = 5
+    feat, wemb = torch.randn(B, D_, side, side, generator=gen), torch.randn(B, D_, T_, generator=gen)
+    lens = torch.tensor([T_, 1, max(1, T_ - 1), 2 if T_ > 1 else 1, T_])
+    cids = [3, 7, 3, 9, 7] if dup else None
+    fr, wr = feat.clone().requires_grad_(True), wemb.clone().requires_grad_(True)
+    lr, maps_r = O.words_loss(fr, wr, torch.arange(B), lens.tolist(), cids)
+    lr.backward()
+    fd, wd = feat.to(DEV).requires_grad_(True), wemb.to(DEV).requires_grad_(True)
+    ld, maps_d = WL(torch.device(DEV)).get_loss(fd, wd, torch.arange(B, device=DEV), lens, cids)
+    ld.backward()
+    assert_close(ld, lr, TOL.tight, "loss")
+    for i, (md, mr) in enumerate(zip(maps_d, maps_r)):
+        assert_close(md, mr, TOL.tight, f"map{i}")
+    assert_close(fd.grad, fr.grad, RTOL, "dfeat")
+    assert_close(wd.grad, wr.grad, RTOL, "dwemb")
+
+
 def test_small_losses_vs_golden():
     KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
     g = load("a10_losses")
