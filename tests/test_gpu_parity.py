@@ -255,6 +255,35 @@ def test_attention_all_masked_row_is_nan_and_metric_shape():
     assert_close(attn[:1], ref_attn, TOL.tight, "attn @128x128")
 
 
+@pytest.mark.parametrize("C,T_,H,W", [(40, 16, 9, 9), (64, 1, 20, 15), (8, 7, 4, 4), (32, 10, 64, 64), (17, 20, 6, 5)])
+def test_attention_backward_shape_limits_vs_oracle(C, T_, H, W):
+    """AttentionModule forward + backward against the oracle at the limits of the backward's MFMA pixel reduction (seq_len <= 16):
+    channel counts that do not fill the last 16-channel chunk, the 64-channel maximum, one word, pixel counts that leave most
+    of a 256-pixel workgroup dead, the metric's 64x64 stage; and one seq_len > 16 case on the butterfly path."""
+    gen = torch.Generator().manual_seed(C * 31 + T_)
+    B, E = 3, 24
+    m = ATT.AttentionModule(C, E).to(DEV)
+    images, words = torch.randn(B, C, H, W, generator=gen), torch.randn(B, E, T_, generator=gen)
+    mask = torch.ones(B, T_, dtype=torch.int64)
+    if T_ > 2:
+        mask[1, T_ // 2:] = 0
+        mask[2, 1] = 0
+    w = m.conv1.weight.detach().cpu().clone()
+    ir, wr, cw = images.clone().requires_grad_(True), words.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ctx_r, attn_r = O.attention_module(ir, wr, cw, mask)
+    pc, pa = probe(ctx_r.shape, 0.1), probe(attn_r.shape, 0.2)
+    ((ctx_r * pc).sum() + (attn_r * pa).sum()).backward()
+    idv, wdv = images.to(DEV).requires_grad_(True), words.to(DEV).requires_grad_(True)
+    m.apply_mask(mask.to(DEV))
+    ctx, attn = m(idv, wdv)
+    ((ctx * pc.to(DEV)).sum() + (attn * pa.to(DEV)).sum()).backward()
+    assert_close(ctx, ctx_r, TOL.tight, "ctx")
+    assert_close(attn, attn_r, TOL.tight, "attn")
+    assert_close(idv.grad, ir.grad, TOL.tight, "d images")
+    assert_close(wdv.grad, wr.grad, TOL.tight, "d words")
+    assert_close(m.conv1.weight.grad, cw.grad, TOL.tight, "d conv1")
+
+
 def test_func_attention_vs_golden():
     g = load("a2_func_attention")
     w, a = ATT.func_attention(cu(g["query"]), cu(g["context"]), 4.0)
