@@ -83,7 +83,7 @@ class GradBuckets:
         self.active = self.world > 1 or (os.environ.get("AGAN_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         if self.active:
             if opt.flat.is_cuda:
-                self.comm_stream = torch.cuda.Stream(device=opt.flat.device)
+                self.comm_stream = torch.cuda.Stream(device=opt.flat.device, priority=-1)      # ahead of the chip-filling compute kernels
             for i, p in enumerate(opt.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
