@@ -26,6 +26,11 @@ _PRECISION = [L.PREC_F32]
 
 
 def set_precision(p: int) -> None:
+    if int(p) != _PRECISION[0]:
+        # the batched re-pack (packed_weight / _repack_group) refreshes EVERY registered pack of a layout family: forget the ones the
+        # old mode registered (they re-register on their next use), or a later mode keeps re-packing layouts nothing reads
+        for rng in _FLAT_RANGES:
+            rng[3], rng[4] = [], None
     _PRECISION[0] = int(p)
 
 
@@ -181,11 +186,15 @@ _PACK_JOB_DTYPE = [("w", "<u8"), ("wk", "<u8"), ("mode", "<i4"), ("cout", "<i4")
                    ("first_block", "<i4")]          # include/agan.h: agan_pack_job
 
 
-def _pack_table(rng):
-    """device job table of a flat buffer's pack entries (built on the host, one H2D copy; rebuilt when an entry is added)"""
+def _pack_table(rng, prec: int):
+    """device job table of a flat buffer's pack entries of ONE layout family (`prec`: the fp32 k-table layouts, or one of the 16-bit
+    patch layouts); built on the host, one H2D copy; rebuilt when an entry is added"""
     import numpy as np
-    entries = rng[3]
-    if rng[4] is None or rng[4][1] != len(entries):
+    entries = [e for e in rng[3] if e["prec"] == prec]
+    if rng[4] is None:
+        rng[4] = {}
+    hit = rng[4].get(prec)
+    if hit is None or hit[1] != len(entries):
         if torch.cuda.is_current_stream_capturing():
             raise L.AganError("packed-weight job table missing during HIP-graph capture: run a warm-up step and "
                               "build_pack_tables() first (GanTrainStep.capture does)")
@@ -195,26 +204,28 @@ def _pack_table(rng):
         for i, e in enumerate(entries):
             cout, cin, kh, kw = e["dims"]
             jobs[i] = (e["ptr"], e["wk"].data_ptr(), e["mode"], cout, cin, kh, kw, first)
-            first += lib.agan_pack_job_blocks(e["mode"], cout, cin, kh, kw)
+            first += lib.agan_pack_job_blocks_prec(e["mode"], cout, cin, kh, kw, prec)
         table = torch.from_numpy(jobs.view(np.uint8).copy()).to(entries[0]["wk"].device)
-        rng[4] = (table, len(entries), first)
-    return rng[4]
+        hit = rng[4][prec] = (table, len(entries), first)
+    return hit
 
 
 def build_pack_tables() -> None:
     """Build every missing job table now (host work + H2D copies), e.g. before capturing a HIP graph."""
     for rng in _FLAT_RANGES:
-        if rng[3]:
-            _pack_table(rng)
+        for prec in sorted({e["prec"] for e in rng[3]}):
+            _pack_table(rng, prec)
 
 
-def _repack_group(rng) -> None:
-    """Re-pack every registered packed weight of one flat buffer in a single launch (agan_pack_weights).  After an optimiser
-    step all of them are stale at once, and most are a few KB: one launch instead of one ~10 us launch per tensor and mode."""
-    table, n, total = _pack_table(rng)
-    L.call("agan_pack_weights", _p(table), n, total, L.PREC_F32, _stream())
+def _repack_group(rng, prec: int) -> None:
+    """Re-pack every registered packed weight of one flat buffer and one layout family in a single launch (agan_pack_weights).
+    After an optimiser step all of them are stale at once, and most are a few KB: one launch instead of one ~10-17 us launch per
+    tensor and mode (1.7 ms per step in the 16-bit modes before they took this path too)."""
+    table, n, total = _pack_table(rng, prec)
+    L.call("agan_pack_weights", _p(table), n, total, prec, _stream())
     for e in rng[3]:
-        e["cache"][e["key"]] = ((e["ptr"], e["tver"], _WEIGHT_EPOCH[0], rng[2]) + e["dims"], e["wk"], rng)
+        if e["prec"] == prec:
+            e["cache"][e["key"]] = ((e["ptr"], e["tver"], _WEIGHT_EPOCH[0], rng[2]) + e["dims"], e["wk"], rng)
 
 
 _EFF_PREC = {}
@@ -244,10 +255,10 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None, prec: Opti
     ver = (ptr, w._version, _WEIGHT_EPOCH[0], rng[2] if rng is not None else -1, cout, cin, kh, kw)
     if hit is not None and hit[0] == ver:
         return hit[1]
-    if hit is not None and rng is not None and prec == L.PREC_F32 and hit[0][:2] == ver[:2] and hit[0][4:] == ver[4:] \
+    if hit is not None and rng is not None and hit[0][:2] == ver[:2] and hit[0][4:] == ver[4:] \
             and any(e["cache"] is cache and e["key"] == key for e in rng[3]):
-        # same tensor, only the optimiser epoch moved: its whole group is stale -> one batched launch
-        _repack_group(rng)
+        # same tensor, only the optimiser epoch moved: its whole group (same layout family) is stale -> one batched launch
+        _repack_group(rng, prec)
         hit = cache[key]
         if hit[0] == ver:
             return hit[1]
@@ -259,13 +270,13 @@ def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None, prec: Opti
     L.call("agan_pack_weight", _p(w), _p(wk), mode, cout, cin, kh, kw, prec, _stream())
     if cache is not None:
         cache[key] = (ver, wk, rng)
-        if rng is not None and prec == L.PREC_F32:
+        if rng is not None:
             ent = next((e for e in rng[3] if e["cache"] is cache and e["key"] == key), None)
             if ent is None:
                 ent = {"cache": cache, "key": key}
                 rng[3].append(ent)
-            ent.update(ptr=ptr, tver=w._version, dims=(cout, cin, kh, kw), mode=mode, wk=wk)
-            rng[4] = None                       # job table is rebuilt at the next batched re-pack
+            ent.update(ptr=ptr, tver=w._version, dims=(cout, cin, kh, kw), mode=mode, wk=wk, prec=prec)
+            rng[4] = None                       # job tables are rebuilt at the next batched re-pack
     return wk
 
 

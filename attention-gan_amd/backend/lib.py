@@ -38,6 +38,7 @@ _SIGNATURES = {
     "agan_timer_arm": (c_int, [_P, _P]),
     "agan_timer_elapsed_ms": (c_int, [_P, _P, _P]),
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
+    "agan_pack_job_blocks_prec": (c_int, [c_int] * 6),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_conv_effective_prec": (c_int, [POINTER(ConvGeom), c_int]),

@@ -825,10 +825,14 @@ int agan_pack_weight(const float* w, void* wkv, int mode, int cout, int cin, int
 }
 
 int agan_pack_job_blocks(int mode, int cout, int cin, int kh, int kw) { return pack_job_blocks(mode, cout, cin, kh, kw); }
+int agan_pack_job_blocks_prec(int mode, int cout, int cin, int kh, int kw, int prec) {
+    return prec == AGAN_PREC_F32 ? pack_job_blocks(mode, cout, cin, kh, kw) : (prec_planes(prec) > 0 ? pack_job_blocks_patch(mode, cout, cin, kh, kw) : 0);
+}
 
 int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, void* stream) {
     AGAN_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "pack_weights: empty job list");
-    AGAN_REQUIRE(prec == AGAN_PREC_F32, "pack_weights: the batched path packs fp32 layouts only (precision mode %d)", prec);
+    AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "pack_weights: unknown precision mode %d", prec);
+    if (prec != AGAN_PREC_F32) return pack_weights_patch(jobs, njobs, total_blocks, prec, as_stream(stream));
     hipLaunchKernelGGL(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), jobs, njobs);
     return check_launch("pack_weights");
 }

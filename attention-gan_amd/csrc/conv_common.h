@@ -16,7 +16,7 @@ struct FastDiv {
     unsigned mul, shift;
     __device__ __forceinline__ int div(int n) const { return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> shift); }
 };
-inline FastDiv make_fastdiv(unsigned d) {
+__host__ __device__ inline FastDiv make_fastdiv(unsigned d) {
     FastDiv f;
     unsigned l = 0;
     while ((1ull << l) < d) ++l;
@@ -292,6 +292,8 @@ PatchPlan make_patch_plan(const Geom& g);
 PatchGather plan_patch_gather(const Geom& g, const PatchPlan& pp);
 size_t patch_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
 int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, hipStream_t st);
+int pack_job_blocks_patch(int mode, int cout, int cin, int kh, int kw);
+int pack_weights_patch(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, hipStream_t st);
 void launch_patch_gather(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp,
                          const PatchGather& p, int prec, int act, const float* lrelu_mask, hipStream_t st, const float* in_amax = nullptr,
                          float* out_amax = nullptr);

@@ -1033,12 +1033,12 @@ __device__ __forceinline__ float packed_value_direct(W4 w4, int mode, int cls, i
         }
     }
 }
+struct PackPlanLite { int IS, NPH, NT, nsteps; };
 template <int ET, int NPL>
-__global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout,
-                                                                int cin, int kh, int kw, int ncls, int Kin, int R, int S, int Nld,
-                                                                const PatchPlan pp, const FastDiv drow, const FastDiv dkk) {
-    __shared__ float tile[16 * kPackTile];
-    const int n0 = blockIdx.x * kPackN, chunk = blockIdx.y, c0 = chunk * kCH;
+__device__ __forceinline__ void pack_patch_tile(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout, int cin, int kh,
+                                                int kw, int ncls, int Kin, int R, int S, int Nld, const PackPlanLite pp, const FastDiv drow,
+                                                const FastDiv dkk, const int nblk, const int chunk, float* tile) {
+    const int n0 = nblk * kPackN, c0 = chunk * kCH;
     const int kk = kh * kw;
     const bool ncout = pack_n_is_cout(mode);
     TileOIHW T;
@@ -1101,6 +1101,46 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
                 reinterpret_cast<u32x4*>(wk)[((((size_t)cls * pp.nsteps + q) * NPL + p) * Nld + n) * 2 + (oct & 1)] = o[p];
         }
     }
+}
+
+template <int ET, int NPL>
+__global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk, int mode, int cout,
+                                                                int cin, int kh, int kw, int ncls, int Kin, int R, int S, int Nld,
+                                                                const PackPlanLite pp, const FastDiv drow, const FastDiv dkk) {
+    __shared__ float tile[16 * kPackTile];
+    pack_patch_tile<ET, NPL>(w, wk, mode, cout, cin, kh, kw, ncls, Kin, R, S, Nld, pp, drow, dkk, (int)blockIdx.x, (int)blockIdx.y, tile);
+}
+
+// Every stale pack of an optimiser in ONE launch (16-bit layouts): job i owns workgroups [first_block, first_block + blocks(i)), each a
+// (16 output columns, 32-channel chunk) tile of pack_patch_tile.  A step re-packs ~100 weight tensors, most of them a few KB: launched one
+// by one they cost 1.7 ms per step at the metric config (17 us each, launch-bound) -- 9 % of the fp16-split step.
+template <int ET, int NPL>
+__global__ __launch_bounds__(256) void pack_patch_jobs_kernel(const agan_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[16 * kPackTile];
+    __shared__ int which;
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < njobs; t += 256) {
+        const int lo = jobs[t].first_block, hi = t + 1 < njobs ? jobs[t + 1].first_block : 0x7fffffff;
+        if (b >= lo && b < hi) which = t;
+    }
+    __syncthreads();
+    const agan_pack_job j = jobs[which];
+    const int local = b - j.first_block;
+    int ncls, K, N, R, S, SY;
+    pack_dims(j.mode, j.cout, j.cin, j.kh, j.kw, ncls, K, N);
+    pack_taps(j.mode, j.kh, j.kw, R, S, SY);
+    PackPlanLite pp;
+    pp.IS = SY;
+    pp.NPH = SY == 2 ? 4 : 1;
+    pp.NT = SY == 2 ? (R / 2) * (S / 2) : R * S;
+    const int Kin = K / (R * S);
+    pp.nsteps = cdiv(Kin, kCH) * pp.NPH * pp.NT * 2;
+    const int Nld = (N + 31) / 32 * 32;
+    const int nbn = cdiv(Nld, kPackN);
+    const FastDiv dkk = make_fastdiv((unsigned)(j.kh * j.kw));
+    const FastDiv drow = make_fastdiv((unsigned)((pack_n_is_cout(j.mode) ? kCH : kPackN) * j.kh * j.kw));
+    pack_patch_tile<ET, NPL>(j.w, static_cast<unsigned short*>(j.wk), j.mode, j.cout, j.cin, j.kh, j.kw, ncls, K, R, S, Nld, pp, drow, dkk,
+                             local % nbn, local / nbn, tile);
 }
 
 template <int ET, int NPL, int BN>
@@ -1296,7 +1336,9 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
     unsigned short* o = static_cast<unsigned short*>(wk);
     const FastDiv dkk = make_fastdiv((unsigned)(kh * kw));
     const FastDiv drow = make_fastdiv((unsigned)((pack_n_is_cout(mode) ? kCH : kPackN) * kh * kw));
-#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pp, drow, dkk)
+    PackPlanLite pl;
+    pl.IS = pp.IS; pl.NPH = pp.NPH; pl.NT = pp.NT; pl.nsteps = pp.nsteps;
+#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pl, drow, dkk)
     switch (prec) {
         case AGAN_PREC_BF16: AGAN_PK(0, 1); break;
         case AGAN_PREC_F16: AGAN_PK(1, 1); break;
@@ -1307,6 +1349,28 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
     }
 #undef AGAN_PK
     return check_launch("pack_weight/patch");
+}
+
+int pack_job_blocks_patch(int mode, int cout, int cin, int kh, int kw) {
+    int ncls, K, N;
+    if (pack_dims(mode, cout, cin, kh, kw, ncls, K, N)) return 0;
+    int R, S, SY;
+    pack_taps(mode, kh, kw, R, S, SY);
+    return cdiv(agan_round_up(N, 32), kPackN) * cdiv(K / (R * S), kCH);
+}
+
+int pack_weights_patch(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, hipStream_t st) {
+#define AGAN_PKJ(ET, NPL) hipLaunchKernelGGL((pack_patch_jobs_kernel<ET, NPL>), dim3(total_blocks), dim3(256), 0, st, jobs, njobs)
+    switch (prec) {
+        case AGAN_PREC_BF16: AGAN_PKJ(0, 1); break;
+        case AGAN_PREC_F16: AGAN_PKJ(1, 1); break;
+        case AGAN_PREC_BF16X3: AGAN_PKJ(0, 2); break;
+        case AGAN_PREC_BF16X6: AGAN_PKJ(0, 3); break;
+        case AGAN_PREC_F16X3: AGAN_PKJ(1, 2); break;
+        default: return AGAN_EINVAL;
+    }
+#undef AGAN_PKJ
+    return check_launch("pack_weights/patch");
 }
 
 PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec) {

@@ -93,7 +93,7 @@ enum {
 size_t agan_packed_weight_bytes(int mode, int cout, int cin, int kh, int kw, int prec);
 /* w: OIHW [cout][cin][kh][kw] -> wk (see modes).  Replaces nothing in the reference: layout prep for the kernels below. */
 int agan_pack_weight(const float* w, void* wk, int mode, int cout, int cin, int kh, int kw, int prec, void* stream);
-/* Many packs in one launch (fp32 layouts): what a module re-packs after an optimiser step.  `jobs` is a DEVICE array; job i owns
+/* Many packs in one launch (all jobs of one call share `prec`, i.e. one layout family): what a module re-packs after an optimiser step.  `jobs` is a DEVICE array; job i owns
  * workgroups [first_block, first_block + agan_pack_job_blocks(...)), first_block ascending from 0; total_blocks = their sum.
  * Same layouts as agan_pack_weight, including zeroed padding columns. */
 typedef struct agan_pack_job {
@@ -102,6 +102,7 @@ typedef struct agan_pack_job {
     int32_t mode, cout, cin, kh, kw, first_block;
 } agan_pack_job;
 int agan_pack_job_blocks(int mode, int cout, int cin, int kh, int kw);
+int agan_pack_job_blocks_prec(int mode, int cout, int cin, int kh, int kw, int prec);   /* ... for a 16-bit layout (prec != AGAN_PREC_F32) */
 int agan_pack_weights(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, void* stream);
 
 /* conv forward / dgrad: replaces F.conv2d fwd+dgrad under Layers.conv3x3 / conv4x4 s2 / Upsample+conv3x3 /
