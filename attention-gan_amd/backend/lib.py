@@ -17,6 +17,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x6": PREC_BF16X6, "f16x3": PREC_F16X3}
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_4x4S2, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+COMM_ID_BYTES = 128    # include/agan.h: AGAN_COMM_ID_BYTES
 AMAX_SLOT = 256        # floats per amax slot (include/agan.h: AGAN_AMAX_SLOT)
 
 
@@ -37,6 +38,10 @@ _SIGNATURES = {
     "agan_timer_destroy": (c_int, [_P]),
     "agan_timer_arm": (c_int, [_P, _P]),
     "agan_timer_elapsed_ms": (c_int, [_P, _P, _P]),
+    "agan_comm_unique_id": (c_int, [_P]),
+    "agan_comm_init": (c_int, [_P, c_int, c_int, _P]),
+    "agan_comm_destroy": (c_int, [_P]),
+    "agan_allreduce_bucket": (c_int, [_P, _P, c_size_t, _P]),
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
     "agan_pack_job_blocks_prec": (c_int, [c_int] * 6),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),

@@ -870,7 +870,6 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
             // of the next item with the MFMAs of this one, tap by tap.
             constexpr int G = (NPL == 1 || TPW <= 5) ? TPW : 3, NG = TPW / G;
             static_assert(TPW % G == 0, "tap groups must tile the taps of a wave");
-            constexpr int kProd = NPL == 1 ? 1 : (NPL == 2 ? 3 : 6);
             u32x4 a[2][NPL], bf[2][G][NPL];
             unsigned xo[2][2];
             xpos(0, xo[0]);

@@ -55,6 +55,47 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None
         dist.broadcast(t.data, src=src, group=group)
 
 
+class DirectRccl:
+    """One RCCL communicator per process, driven through the C ABI (include/agan.h: agan_comm_* / agan_allreduce_bucket): each bucket
+    goes out as reduce-scatter + all-gather on the bucket's comm stream.  Opt-in (AGAN_RCCL_DIRECT=1); the default exchange is
+    torch.distributed's all_reduce, which is also what the CPU (gloo) tests can run.  The id travels over the existing process
+    group, whatever its backend."""
+
+    _shared: dict = {}
+
+    def __init__(self, group=None):
+        import ctypes
+        from .backend import lib as L
+        self.L = L
+        rank, world = rank_of(group), world_size(group)
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+            L.call("agan_comm_unique_id", buf)
+            ident[0] = bytes(buf.raw)
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        self._id = ctypes.create_string_buffer(ident[0], L.COMM_ID_BYTES)
+        self.comm = ctypes.c_void_p()
+        L.call("agan_comm_init", ctypes.byref(self.comm), rank, world, self._id)
+
+    @classmethod
+    def get(cls, group=None):
+        key = id(group)
+        if key not in cls._shared:
+            cls._shared[key] = cls(group)
+        return cls._shared[key]
+
+    def all_reduce_(self, chunk: torch.Tensor, stream: torch.cuda.Stream) -> None:
+        import ctypes
+        self.L.call("agan_allreduce_bucket", self.comm, ctypes.c_void_p(chunk.data_ptr()), chunk.numel(), ctypes.c_void_p(stream.cuda_stream))
+
+    def close(self) -> None:
+        if self.comm:
+            self.L.call("agan_comm_destroy", self.comm)
+            self.comm = None
+
+
 class GradBuckets:
     """Bucketed, backward-overlapped all-reduce over a FlatAdam's flat gradient buffer."""
 
@@ -81,6 +122,7 @@ class GradBuckets:
         # AGAN_DP_FORCE=1: run the whole exchange machinery (hooks, comm stream, async handles) in a world of ONE rank as well --
         # the rehearsal of the `nccl` backend that a one-GPU box allows (RCCL refuses two ranks on one device)
         self.active = self.world > 1 or (os.environ.get("AGAN_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+        self.direct = DirectRccl.get(group) if (self.active and opt.flat.is_cuda and os.environ.get("AGAN_RCCL_DIRECT") == "1") else None
         if self.active:
             if opt.flat.is_cuda:
                 self.comm_stream = torch.cuda.Stream(device=opt.flat.device, priority=-1)      # ahead of the chip-filling compute kernels
@@ -110,6 +152,10 @@ class GradBuckets:
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             HF.join_all_side_streams(self.comm_stream)          # weight gradients forked onto side streams
+            if self.direct is not None:
+                chunk.record_stream(self.comm_stream)
+                self.direct.all_reduce_(chunk, self.comm_stream)      # joined in finish() through the comm stream
+                return
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

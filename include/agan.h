@@ -265,6 +265,20 @@ int agan_timer_elapsed_ms(void* start, void* stop, float* ms);
 
 static inline int agan_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL (new component: the reference is single-GPU).
+ * One communicator per process (one process per GPU).  Rank 0 makes the id and hands its AGAN_COMM_ID_BYTES bytes to every rank out
+ * of band (the Python host uses torch.distributed's store); agan_comm_init is collective over all ranks and binds the calling
+ * thread's current device.  agan_allreduce_bucket sums `n` floats in place across the ranks on `stream` (reduce-scatter + all-gather
+ * when n divides evenly, else one all-reduce call); the 1/world scale is applied by agan_adam_step's grad_scale.
+ * RCCL is bound at run time: without a loadable librccl these calls return AGAN_EINVAL and nothing else is affected.
+ * ---------------------------------------------------------------------------------------------- */
+#define AGAN_COMM_ID_BYTES 128
+int agan_comm_unique_id(void* id);
+int agan_comm_init(void** comm, int rank, int world, const void* id);
+int agan_comm_destroy(void* comm);
+int agan_allreduce_bucket(void* comm, float* buf, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

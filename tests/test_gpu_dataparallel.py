@@ -196,3 +196,47 @@ def test_one_rank_nccl_exchange_is_identity():
     assert float(out["g_total"]) == g_total
     for k, v in G.state_dict().items():
         assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
+
+
+def _direct_rccl_worker(port, q):
+    """the same one-rank rehearsal with the exchange driven through the C ABI (agan_comm_init / agan_allreduce_bucket: reduce-scatter +
+    all-gather per bucket on the comm stream) instead of torch.distributed's all_reduce"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AGAN_DP_FORCE="1", AGAN_RCCL_DIRECT="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=0, world_size=1)          # only carries the communicator id
+    try:
+        G, Ds, enc = _nets(dev)
+        step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=64 << 10)
+        assert step.g_buckets.direct is not None and len(step.g_buckets.bounds) > 1
+        words, sent, lens, reals, noise, eps = _shard(0, dev)
+        for _ in range(2):
+            out = step.step(words, sent, lens, None, reals, noise, eps)
+        torch.cuda.synchronize()
+        q.put(({k: v.detach().cpu().numpy() for k, v in G.state_dict().items()}, float(out["g_total"])))
+        step.g_buckets.direct.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_direct_rccl_exchange_is_identity():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_direct_rccl_worker, args=(free_port(), q))
+    p.start()
+    g_sd, g_total = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    dev = torch.device("cuda", 0)
+    G, Ds, enc = _nets(dev)
+    step = TR.GanTrainStep(G, Ds, enc)
+    words, sent, lens, reals, noise, eps = _shard(0, dev)
+    for _ in range(2):
+        out = step.step(words, sent, lens, None, reals, noise, eps)
+    torch.cuda.synchronize()
+    assert float(out["g_total"]) == g_total
+    for k, v in G.state_dict().items():
+        assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
