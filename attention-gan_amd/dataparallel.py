@@ -78,6 +78,9 @@ class DirectRccl:
         self._id = ctypes.create_string_buffer(ident[0], L.COMM_ID_BYTES)
         self.comm = ctypes.c_void_p()
         L.call("agan_comm_init", ctypes.byref(self.comm), rank, world, self._id)
+        # ONE stream for every collective of this communicator (the generator's and the three discriminators' buckets): RCCL orders
+        # the operations of a communicator by issue order, and one stream makes that order explicit on the device as well
+        self.stream = torch.cuda.Stream(priority=-1)
 
     @classmethod
     def get(cls, group=None):
@@ -124,7 +127,9 @@ class GradBuckets:
         self.active = self.world > 1 or (os.environ.get("AGAN_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         self.direct = DirectRccl.get(group) if (self.active and opt.flat.is_cuda and os.environ.get("AGAN_RCCL_DIRECT") == "1") else None
         if self.active:
-            if opt.flat.is_cuda:
+            if self.direct is not None:
+                self.comm_stream = self.direct.stream
+            elif opt.flat.is_cuda:
                 self.comm_stream = torch.cuda.Stream(device=opt.flat.device, priority=-1)      # ahead of the chip-filling compute kernels
             for i, p in enumerate(opt.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
