@@ -86,7 +86,11 @@ def _grad_out(dst, shape, like: Tensor):
     if dst is None:
         t = torch.empty(shape, dtype=torch.float32, device=like.device)
         return t, 0, t
+    if dst.locked:
+        raise L.AganError("a backward kernel is about to write into a flat gradient slice whose bucket is already being all-reduced: "
+                          "call zero_grad() (and GradBuckets.arm()) before running another backward under data parallelism")
     view = dst.flat[dst.offset:dst.offset + dst.numel].view(shape)
+    dst.edges += 1
     if dst.written:
         return view, 1, None
     dst.written = True
@@ -94,11 +98,16 @@ def _grad_out(dst, shape, like: Tensor):
 
 
 class GradDst:
-    """Slice of a FlatAdam gradient buffer that belongs to one parameter (+ 'already written in this backward' flag)."""
-    __slots__ = ("flat", "offset", "numel", "written")
+    """Slice of a FlatAdam gradient buffer that belongs to one parameter.  `written`: a kernel has produced the slice in this
+    backward; `edges`: how many kernel contributions went into it (FlatAdam._rebind tells a harmless autograd clone from a summed
+    stock edge with it); `locked`: the slice's bucket has been handed to the gradient exchange (GradBuckets._launch)."""
+    __slots__ = ("flat", "offset", "numel", "written", "edges", "locked")
 
     def __init__(self, flat: Tensor, offset: int, numel: int):
-        self.flat, self.offset, self.numel, self.written = flat, offset, numel, False
+        self.flat, self.offset, self.numel, self.written, self.edges, self.locked = flat, offset, numel, False, 0, False
+
+    def reset(self) -> None:
+        self.written, self.edges, self.locked = False, 0, False
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -731,7 +740,11 @@ class _AttentionFn(Function):
         dctx = _dev(dctx, "attention dctx") if dctx is not None else None
         dattn = _dev(dattn, "attention dattn") if dattn is not None else None
         dimages, dwords = torch.empty_like(images), torch.empty_like(words)
-        dwbuf, wacc, dw = _grad_out(ctx.wdst, w.shape, images)
+        # a frozen projection (requires_grad False) still needs d(proj) for nothing: its gradient goes to scratch, not into the
+        # owner's flat buffer (as the conv and BatchNorm paths do)
+        dwbuf, wacc, dw = _grad_out(ctx.wdst if ctx.needs_input_grad[2] else None, w.shape, images)
+        if not ctx.needs_input_grad[2]:
+            dw = None
         nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T, H * W)
         ws, wsp = _ws(nbytes, images)
         L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
@@ -871,6 +884,18 @@ def _ids(class_ids, device) -> Optional[Tensor]:
     return torch.as_tensor(class_ids).to(device=device, dtype=torch.int64).contiguous()
 
 
+def _labels(labels, batch: int, device) -> Optional[Tensor]:
+    """CE targets for the kernels (words_loss.py:98-99, sentence_loss.py:46-47): an int64 device vector, or None for arange(batch)
+    (the kernels' built-in default -- what train.py:104 / _make_match_labels builds, recognised by the `_agan_arange` tag so that
+    the hot path neither copies nor reads the labels back)."""
+    if labels is None or getattr(labels, "_agan_arange", None) == batch:
+        return None
+    lab = torch.as_tensor(labels).reshape(-1)
+    if lab.numel() != batch:
+        raise ValueError(f"labels must have one entry per sample (got {lab.numel()} for a batch of {batch})")
+    return lab.to(device=device, dtype=torch.int64).contiguous()
+
+
 class _FuncAttentionFn(Function):
     @staticmethod
     def forward(ctx, query, context, gamma1, scale):
@@ -909,7 +934,7 @@ def func_attention(query: Tensor, context: Tensor, gamma1: float = 4.0, scaled: 
 
 class _WordsLossFn(Function):
     @staticmethod
-    def forward(ctx, feat, wemb, lens, cids, g1, g2, g3, lam):
+    def forward(ctx, feat, wemb, lens, cids, labels, g1, g2, g3, lam):
         feat, wemb = _dev(feat, "img_features"), _dev(wemb, "words_emb")
         B, D = feat.shape[0], feat.shape[1]
         S = feat.numel() // (B * D)
@@ -918,7 +943,7 @@ class _WordsLossFn(Function):
         sim = torch.empty((B, B), dtype=torch.float32, device=feat.device)
         maps = torch.zeros((B, T, S), dtype=torch.float32, device=feat.device)
         save = torch.empty(L.load().agan_words_loss_save_elems(B, D, T, S), dtype=torch.float32, device=feat.device)
-        L.call("agan_words_loss_fwd", _p(feat), _p(wemb), _p(lens), _p(cids), g1, g2, g3, lam, _p(loss), _p(sim), _p(maps),
+        L.call("agan_words_loss_fwd", _p(feat), _p(wemb), _p(lens), _p(cids), _p(labels), g1, g2, g3, lam, _p(loss), _p(sim), _p(maps),
                _p(save), B, D, T, S, _stream())
         ctx.save_for_backward(feat, wemb, lens, save)
         ctx.hp = (g1, g2, g3, lam)
@@ -938,26 +963,26 @@ class _WordsLossFn(Function):
         ws, wsp = _ws(nbytes, feat)
         L.call("agan_words_loss_bwd", _p(feat), _p(wemb), _p(lens), _p(save), _p(dl), *ctx.hp, _p(dfeat), _p(dwemb),
                B, D, T, S, wsp, nbytes, _stream())
-        return dfeat, dwemb, None, None, None, None, None, None
+        return dfeat, dwemb, None, None, None, None, None, None, None
 
 
-def words_loss(feat, wemb, cap_lens, class_ids, gamma1, gamma2, gamma3, wlambda):
+def words_loss(feat, wemb, cap_lens, class_ids, gamma1, gamma2, gamma3, wlambda, labels=None):
     if isinstance(cap_lens, Tensor) and cap_lens.is_cuda and cap_lens.dtype == torch.int64:
         lens = cap_lens.contiguous()                       # already resident: no host round trip (HIP-graph capturable)
     else:
         lens = torch.as_tensor(cap_lens).to(device=feat.device, dtype=torch.int64).contiguous()
-    return _WordsLossFn.apply(feat, wemb, lens, _ids(class_ids, feat.device), float(gamma1), float(gamma2), float(gamma3),
-                              float(wlambda))
+    return _WordsLossFn.apply(feat, wemb, lens, _ids(class_ids, feat.device), _labels(labels, feat.shape[0], feat.device),
+                              float(gamma1), float(gamma2), float(gamma3), float(wlambda))
 
 
 class _SentLossFn(Function):
     @staticmethod
-    def forward(ctx, cnn, rnn, cids, g3, lam, eps):
+    def forward(ctx, cnn, rnn, cids, labels, g3, lam, eps):
         cnn, rnn = _dev(cnn, "cnn_code"), _dev(rnn, "rnn_code")
         B, D = cnn.shape
         loss = torch.empty((), dtype=torch.float32, device=cnn.device)
         save = torch.empty(2 * B * B + 2 * B, dtype=torch.float32, device=cnn.device)
-        L.call("agan_sent_loss_fwd", _p(cnn), _p(rnn), _p(cids), g3, lam, eps, _p(loss), _p(save), B, D, _stream())
+        L.call("agan_sent_loss_fwd", _p(cnn), _p(rnn), _p(cids), _p(labels), g3, lam, eps, _p(loss), _p(save), B, D, _stream())
         ctx.save_for_backward(cnn, rnn, save)
         ctx.hp = (g3, lam, eps)
         return loss
@@ -970,11 +995,12 @@ class _SentLossFn(Function):
         dc, dr = torch.empty_like(cnn), torch.empty_like(rnn)
         dl = dloss.to(torch.float32).contiguous()
         L.call("agan_sent_loss_bwd", _p(cnn), _p(rnn), _p(save), _p(dl), *ctx.hp, _p(dc), _p(dr), B, D, _stream())
-        return dc, dr, None, None, None, None
+        return dc, dr, None, None, None, None, None
 
 
-def sentence_loss(cnn_code, rnn_code, class_ids, gamma3, slambda, eps=1e-8):
-    return _SentLossFn.apply(cnn_code, rnn_code, _ids(class_ids, cnn_code.device), float(gamma3), float(slambda), float(eps))
+def sentence_loss(cnn_code, rnn_code, class_ids, gamma3, slambda, eps=1e-8, labels=None):
+    return _SentLossFn.apply(cnn_code, rnn_code, _ids(class_ids, cnn_code.device), _labels(labels, cnn_code.shape[0], cnn_code.device),
+                             float(gamma3), float(slambda), float(eps))
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "agan_comm_init": (c_int, [_P, c_int, c_int, _P]),
     "agan_comm_destroy": (c_int, [_P]),
     "agan_allreduce_bucket": (c_int, [_P, _P, c_size_t, _P]),
+    "agan_allreduce_chunk_elems": (c_size_t, [c_size_t, c_int]),
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
     "agan_pack_job_blocks_prec": (c_int, [c_int] * 6),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
@@ -73,10 +74,10 @@ _SIGNATURES = {
     "agan_func_attention_fwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_func_attention_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_words_loss_save_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "agan_words_loss_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "agan_words_loss_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_words_loss_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "agan_words_loss_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
-    "agan_sent_loss_fwd": (c_int, [_P, _P, _P, c_float, c_float, c_float, _P, _P, c_int, c_int, _P]),
+    "agan_sent_loss_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, c_int, c_int, _P]),
     "agan_sent_loss_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, c_int, c_int, _P]),
     "agan_disc_loss": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "agan_gen_loss": (c_int, [_P, _P, _P, c_int, _P]),

@@ -34,9 +34,16 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // first the copy the process ALREADY carries (torch's): RTLD_NOLOAD never maps a second RCCL beside it; only a process
+        // without one (a plain C++ host) loads the ROCm library
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.handle) break;
+        }
+        for (const char* name : names) {
+            if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.handle) return;
 #define AGAN_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, #sym))
@@ -102,14 +109,19 @@ int agan_comm_destroy(void* comm) {
     return rc == ncclSuccess ? AGAN_OK : fail("comm_destroy", rc);
 }
 
+size_t agan_allreduce_chunk_elems(size_t n, int world) {
+    // buckets are slices of FlatAdam's flat gradient buffer (16-byte aligned parameters): an even split into 16-byte aligned
+    // chunks, one per rank (rank r owns [r * chunk, (r + 1) * chunk)), or 0 = no such split -> the library's all-reduce
+    if (world < 1 || n == 0) return 0;
+    if (n % (size_t)world != 0 || (n / (size_t)world) % 4 != 0) return 0;
+    return n / (size_t)world;
+}
+
 int agan_allreduce_bucket(void* comm, float* buf, size_t n, void* stream) {
     AGAN_REQUIRE(comm && buf && n > 0, "allreduce_bucket: bad argument");
     Comm* c = static_cast<Comm*>(comm);
     hipStream_t st = as_stream(stream);
-    // buckets are slices of FlatAdam's flat gradient buffer (16-byte aligned parameters): split evenly when the element count
-    // allows, else fall back to the library's all-reduce for this bucket
-    if (n % (size_t)c->world == 0 && (n / c->world) % 4 == 0) {
-        const size_t chunk = n / c->world;
+    if (const size_t chunk = agan_allreduce_chunk_elems(n, c->world)) {
         float* mine = buf + (size_t)c->rank * chunk;
         ncclResult_t rc = rccl().ReduceScatter(buf, mine, chunk, ncclFloat, ncclSum, c->comm, st);      // in place: recv = send + rank * chunk
         if (rc != ncclSuccess) return fail("allreduce_bucket/reduce_scatter", rc);

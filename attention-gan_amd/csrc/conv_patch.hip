@@ -44,7 +44,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kCH = 32;             // channels per stage
 constexpr int kPosBytes = 80;       // LDS bytes per patch position and plane
 constexpr int kMaxPos = 320;        // positions a patch may have (host checks)
-constexpr int kPlaneBytes = kMaxPos * kPosBytes;
 constexpr int kItems = (kMaxPos * (kCH / 8) + 255) / 256;     // (position, channel octet) staging items per thread
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access (vmcnt(0)),
@@ -125,200 +124,8 @@ __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&w)[NPL], const u32x4 
 // ================================================================================================
 // forward / data-gradient kernel
 // ================================================================================================
-#ifndef AGAN_PATCH_OCC1
-#define AGAN_PATCH_OCC1 3
-#endif
-template <int ET, int NPL, int BN, int NT>
-__global__ __launch_bounds__(256, NPL == 1 ? AGAN_PATCH_OCC1 : 2) void conv_patch_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wk,
-                                                         const float* __restrict__ bias, float* __restrict__ out, const Geom g,
-                                                         const PatchPlan pp, const int ksplit, const int stages_per_split,
-                                                         const size_t slab, const int act, const float* __restrict__ lrelu_mask) {
-    constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;        // each wave: 32 output channels x TM x 32 pixels
-    constexpr int SPS = 2 * NT;                                   // k-steps (16 channels of one tap) per stage
-    __shared__ __attribute__((aligned(16))) unsigned char patch[NPL * kPlaneBytes];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN, wm = wave / WN;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    // ---- tile of this workgroup (XCD-aware order as in conv.hip: channel tile fastest, then parity class, pixel tile, K split) ----
-    int mt, nt, cls, split;
-    {
-        const int ncls = gridDim.z / ksplit, mtiles = gridDim.x, ntiles = gridDim.y;
-        int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * (int)gridDim.z);
-        nt = F % ntiles; F /= ntiles;
-        cls = F % ncls;  F /= ncls;
-        mt = F % mtiles; split = F / mtiles;
-    }
-    const int py = cls / g.OS, px = cls - py * g.OS;
-    const int n0 = nt * BN;
-    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
-    const int twl = pp.twl, thl = pp.thl;
-    const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
-    const int ihw = g.IH * g.IW;
-    const int stage_beg = split * stages_per_split, stage_end = min(pp.nstages, stage_beg + stages_per_split);
-
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
-    const size_t wbytes_cls = (size_t)pp.nsteps * NPL * g.Nld * 32;                 // bytes of one class's packed weights
-    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)cls * wbytes_cls, wbytes_cls);
-
-    // ---- staging items: (patch position, channel octet) -> registers hold what does not change between stages -------------
-    int it_iy[kItems], it_ix[kItems], it_cb[kItems];      // input row/col of the position for phase offset 0; (b*Cin + oct*8)*ihw or -1
-    unsigned it_lds[kItems];
-    int it_oct[kItems];
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const int e = tid + i * 256;
-        const int oct = pp.dPP.div(e), p = e - oct * pp.PP;
-        const int pb = pp.dPHW.div(p), rem = p - pb * pp.PHW;
-        const int j = pp.dPW.div(rem), ii = rem - j * pp.PW;
-        const int b = tb0 + pb;
-        const bool ok = (oct < kCH / 8) & (b < g.B);
-        it_iy[i] = pp.IS * (ty0 + j);
-        it_ix[i] = pp.IS * (tx0 + ii);
-        it_cb[i] = ok ? (b * g.Cin + oct * 8) * ihw : -1;
-        it_oct[i] = oct;
-        it_lds[i] = (unsigned)(p * kPosBytes + oct * 16);
-    }
-    float sreg[kItems][8];
-    const bool cin8 = (g.Cin & 7) == 0;
-
-    auto load_patch = [&](int stage) {
-        const int chunk = stage / pp.NPH, ph = stage - chunk * pp.NPH;
-        const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
-        const int c0 = chunk * kCH;
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            const int iy = it_iy[i] + by, ix = it_ix[i] + bx;
-            const bool ok = (it_cb[i] >= 0) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-            const int nrem = g.Cin - c0 - it_oct[i] * 8;                    // channels of this octet that exist
-            const unsigned voff = (ok & (nrem > 0)) ? (unsigned)(it_cb[i] + c0 * ihw + iy * g.IW + ix) * 4u : kOOB;
-            if (cin8) {                                                     // whole octets only: no per-channel test
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, voff, (unsigned)(c * ihw) * 4u);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sreg[i][c] = buf_load_s(rin, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
-            }
-        }
-    };
-    auto store_patch = [&]() {
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            if (it_oct[i] < kCH / 8) {          // (items past the patch decode to octet >= 4: nothing to store)
-                u32x4 v[NPL];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned pl[NPL];
-                    split_pack2<ET, NPL>(sreg[i][2 * c], sreg[i][2 * c + 1], pl);
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
-                }
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(patch + q * kPlaneBytes + it_lds[i]) = v[q];
-            }
-        }
-    };
-
-    // ---- MFMA operand addresses -----------------------------------------------------------------------------------------------
-    unsigned lbase[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int l = (wm * TM + t) * 32 + l31;
-        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-        lbase[t] = (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * kPosBytes + lh * 16);
-    }
-    // byte offset inside a [Nld][16] weight block (rows past Nld only feed accumulator rows that are never stored: clamp)
-    const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
-    const unsigned wstep = (unsigned)(NPL * g.Nld * 32);                         // bytes per k-step
-    u32x4 wf[2][NPL];
-    const int qlast = pp.nsteps - 1;
-    auto load_w = [&](int slot, int q) {       // (the scalar offset is not range-checked by the buffer unit: clamp the step)
-        const unsigned so = (unsigned)min(q, qlast) * wstep;
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) wf[slot][p] = buf_load_u4s(rwk, wlane, so + (unsigned)(p * g.Nld * 32));
-    };
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    if (stage_beg < stage_end) {
-        int q = stage_beg * SPS;
-        load_w(0, q);
-        load_w(1, q + 1);
-        load_patch(stage_beg);
-        store_patch();
-        __syncthreads();
-        for (int stage = stage_beg; stage < stage_end; ++stage) {
-            const bool more = stage + 1 < stage_end;
-            if (more) load_patch(stage + 1);
-#pragma unroll
-            for (int u = 0; u < SPS; ++u) {
-                const int t = u >> 1, cb = u & 1;
-                u32x4 w[NPL];
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) w[p] = wf[u & 1][p];
-                load_w(u & 1, q + 2);                                   // two k-steps ahead (past the end: unused / zero)
-                ++q;
-#pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    u32x4 a[NPL];
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p)
-                        a[p] = *reinterpret_cast<const u32x4*>(patch + p * kPlaneBytes + lbase[m] + pp.tapoff[t] + cb * 32);
-                    acc[m] = mfma_split<ET, NPL>(w, a, acc[m]);
-                }
-            }
-            __syncthreads();                  // every wave is done reading this stage's patch
-            if (more) {
-                store_patch();
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ------------------------------
-    const size_t ohw = (size_t)g.OH * g.OW;
-    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
-    const bool add_bias = (bias != nullptr) && (ksplit == 1);
-    const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);
-    const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
-    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
-    // per-lane part of the address in the vector offset (pixel, and the 4*lh channel rows of this half-wave); the channel of
-    // accumulator register r is wave-uniform and goes into the instruction's scalar offset: no per-store address arithmetic
-    const int nw = n0 + wn * 32;
-    const bool nfull = nw + 32 <= g.Cout;                    // whole 32-channel block inside the tensor (the common case)
-    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : dst, (size_t)g.Cout * sizeof(float));
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int l = (wm * TM + t) * 32 + l31;
-        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-        const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
-        const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
-        const unsigned pixoff = (unsigned)(b * g.Cout + nw + 4 * lh) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
-        const unsigned voff = pvalid ? pixoff * 4u : kOOB;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            constexpr int dummy = 0; (void)dummy;
-            const int nr = (r & 3) + 8 * (r >> 2);           // channel row of register r inside the block (+ 4*lh, per lane)
-            float v = acc[t][r];
-            if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
-            if (lrelu) v = v > 0.f ? v : 0.2f * v;
-            const unsigned so = (unsigned)nr * (unsigned)ohw * 4u;
-            const unsigned vo = (nfull || (nw + nr + 4 * lh < g.Cout)) ? voff : kOOB;
-            if (masked) v = buf_load_s(rmask, vo, so) > 0.f ? v : 0.2f * v;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, so, 0);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Second generation of the gather kernel: the patch is DOUBLE-BUFFERED in LDS and the conversion + LDS store of the next stage's
+// The gather kernel (the first generation -- single-buffered patch, two barriers per stage -- was removed in round 3): the patch is DOUBLE-BUFFERED in LDS and the conversion + LDS store of the next stage's
 // patch is issued item by item BETWEEN the MFMA k-steps of the current stage (an MFMA occupies the vector issue port for 8 of
 // its 32 cycles, so the ~500 VALU instructions of a three-plane conversion disappear behind the matrix pipe instead of
 // standing between two barriers), which leaves ONE barrier per stage.  The three-plane mode stages 16 channels at a time (48-byte
@@ -563,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
         }
     }
 
-    // ---- epilogue (as conv_patch_kernel) ----
+    // ---- epilogue ----
     const size_t ohw = (size_t)g.OH * g.OW;
     float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
@@ -1088,7 +895,10 @@ __device__ __forceinline__ void pack_patch_tile(const float* __restrict__ w, uns
             for (int c = 0; c < 2; ++c)
                 v[c] = (nvalid && ch + 2 * c2 + c < nchan) ? packed_value_direct(T, mode, cls, ch + 2 * c2 + c, r, sx, n, kh, kw) : 0.f;
             unsigned pl[NPL];
-            if (ET == 1 && NPL == 2) split_pack2<ET, NPL>(v[0] * kF16WeightScale, v[1] * kF16WeightScale, pl);
+            // (f16x3: weights travel times 2^11; |w| >= 32 would leave fp16's range -- saturate at the largest finite fp16 instead of
+            // packing an infinity that turns every output it touches into NaN)
+            if (ET == 1 && NPL == 2) split_pack2<ET, NPL>(fminf(fmaxf(v[0] * kF16WeightScale, -65504.f), 65504.f),
+                                                          fminf(fmaxf(v[1] * kF16WeightScale, -65504.f), 65504.f), pl);
             else split_pack2<ET, NPL>(v[0], v[1], pl);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) o[p][c2] = pl[p];
@@ -1147,26 +957,18 @@ void launch_nt(const float* in, const void* wk, const float* bias, float* dst, c
                int act, const float* mask, hipStream_t st, const float* in_scale, float* out_amax) {
     dim3 grid(pp.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
-    static const bool v1 = getenv("AGAN_PATCH_V1") != nullptr;
-    if (!v1) {
-        constexpr int PB = (NPL >= 3 ? 16 : 32) * 2 + 16;
-        const int plane = (pp.PP + 7) / 8 * 8 * PB;
-        const size_t smem = (size_t)2 * NPL * plane;
-        if (pp.NT == 9) {
-            static const hipError_t a9 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)a9;
-            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
-        } else {
-            static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)a4;
-            hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
-        }
-        return;
+    constexpr int PB = (NPL >= 3 ? 16 : 32) * 2 + 16;
+    const int plane = (pp.PP + 7) / 8 * 8 * PB;
+    const size_t smem = (size_t)2 * NPL * plane;
+    if (pp.NT == 9) {
+        static const hipError_t a9 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)a9;
+        hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
+    } else {
+        static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)a4;
+        hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
     }
-    if (pp.NT == 9)
-        hipLaunchKernelGGL((conv_patch_kernel<ET, NPL, BN, 9>), grid, dim3(256), 0, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask);
-    else
-        hipLaunchKernelGGL((conv_patch_kernel<ET, NPL, BN, 4>), grid, dim3(256), 0, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask);
 }
 template <int ET, int NPL>
 void launch_bn(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,

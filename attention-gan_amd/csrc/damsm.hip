@@ -501,10 +501,11 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(AGAN_PAIR_M
     }
 }
 
-// Two cross-entropies over a [B][B] similarity matrix with labels = arange, optional same-class mask.
-// Writes loss and dS = d loss / d S (before the upstream gradient).  One workgroup.
-__global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const int64_t* __restrict__ cids, float lambda,
-                                                             float* __restrict__ loss, float* dS, int B) {
+// Two cross-entropies over a [B][B] similarity matrix, CE(S, labels) + CE(S^T, labels) (words_loss.py:98-99, sentence_loss.py:46-47),
+// optional same-class mask.  labels == nullptr means arange(B) (what train.py:104 passes); a label outside [0, B) poisons the loss
+// with NaN (torch raises there).  Writes loss and dS = d loss / d S (before the upstream gradient).  One workgroup.
+__global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const int64_t* __restrict__ cids, const int64_t* __restrict__ labels,
+                                                             float lambda, float* __restrict__ loss, float* dS, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* S = reinterpret_cast<float*>(smem_raw);      // [B][B]
     float* rlse = S + B * B;                            // [B] row logsumexp
@@ -529,7 +530,11 @@ __global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const i
     }
     __syncthreads();
     float part = 0.f;
-    for (int q = threadIdx.x; q < B; q += 256) part += (rlse[q] - S[q * B + q]) + (clse[q] - S[q * B + q]);
+    for (int q = threadIdx.x; q < B; q += 256) {
+        const long long lq = labels ? (long long)labels[q] : q;
+        if (lq < 0 || lq >= B) part = NAN;
+        else part += (rlse[q] - S[q * B + (int)lq]) + (clse[q] - S[(int)lq * B + q]);     // S^T[q][l] = S[l][q]
+    }
     part = block_sum<256>(part, red);
     if (threadIdx.x == 0) loss[0] = part / B * lambda;
     const float sc = lambda / B;
@@ -538,7 +543,9 @@ __global__ __launch_bounds__(256) void contrastive_ce_kernel(float* sim, const i
         const float v = S[e];
         float g = 0.f;
         if (v > -INFINITY) g = expf(v - rlse[r]) + expf(v - clse[c]);
-        if (r == c) g -= 2.f;
+        const long long lr = labels ? (long long)labels[r] : r, lc = labels ? (long long)labels[c] : c;
+        if (c == lr) g -= 1.f;
+        if (r == lc) g -= 1.f;
         dS[e] = g * sc;
     }
 }
@@ -908,7 +915,7 @@ size_t agan_words_loss_save_elems(int B, int D, int T, int S) {      // dS, tran
     return (size_t)B * B + (size_t)B * D * S + (pair_mfma_ok(D, T, S) ? (size_t)B * D * kMS : 0);
 }
 
-int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, float gamma1,
+int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, const int64_t* labels, float gamma1,
                         float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps, float* save, int B,
                         int D, int T, int S, void* stream) {
     AGAN_REQUIRE(feat && wemb && lens && loss && sim && attn_maps && save, "words_loss_fwd: null pointer");
@@ -940,7 +947,7 @@ int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* len
     else AGAN_PAIR_FWD(32, kNT);
 #undef AGAN_PAIR_FWD
     allow_ce_smem();
-    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, lambda, loss, save, B);
+    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, sim, class_ids, labels, lambda, loss, save, B);
     return check_launch("words_loss_fwd");
 }
 
@@ -986,7 +993,7 @@ int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* len
     return check_launch("words_loss_bwd");
 }
 
-int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, float gamma3, float lambda, float eps,
+int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, const int64_t* labels, float gamma3, float lambda, float eps,
                        float* loss, float* save, int B, int D, void* stream) {
     AGAN_REQUIRE(cnn_code && rnn_code && loss && save, "sent_loss_fwd: null pointer");
     AGAN_REQUIRE(B >= 1 && B <= kMaxB && D >= 1, "sent_loss: batch %d out of range", B);
@@ -997,7 +1004,7 @@ int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64
     // sim is staged in dS's storage, then overwritten by the CE kernel's gradient
     hipLaunchKernelGGL(sent_scores_kernel, dim3(B), dim3(256), 0, st, cnn_code, rnn_code, gamma3, eps, dS, dots, norms, B, D);
     allow_ce_smem();
-    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, dS, class_ids, lambda, loss, dS, B);
+    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), (size_t)(B * B + 2 * B) * sizeof(float), st, dS, class_ids, labels, lambda, loss, dS, B);
     return check_launch("sent_loss_fwd");
 }
 

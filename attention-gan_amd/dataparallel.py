@@ -47,6 +47,24 @@ def sync_buffers_(module: torch.nn.Module, group=None) -> None:
         o += b.numel()
 
 
+@torch.no_grad()
+def averaged_buffers(module: torch.nn.Module, group=None) -> dict:
+    """{buffer name: mean over the replicas} for the floating-point buffers of `module`, WITHOUT touching the live buffers (a
+    checkpoint must not change the run it is taken from).  A collective: every rank of `group` must call it."""
+    w = world_size(group)
+    named = [(k, b) for k, b in module.named_buffers() if b.is_floating_point()]
+    if w == 1 or not named:
+        return {k: b.detach().clone() for k, b in named}
+    flat = torch.cat([b.reshape(-1) for _, b in named])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(w)
+    out, o = {}, 0
+    for k, b in named:
+        out[k] = flat[o:o + b.numel()].view_as(b).clone()
+        o += b.numel()
+    return out
+
+
 def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Identical initial weights and BN buffers on every replica."""
     if world_size(group) == 1:
@@ -56,12 +74,13 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None
 
 
 class DirectRccl:
-    """One RCCL communicator per process, driven through the C ABI (include/agan.h: agan_comm_* / agan_allreduce_bucket): each bucket
-    goes out as reduce-scatter + all-gather on the bucket's comm stream.  Opt-in (AGAN_RCCL_DIRECT=1); the default exchange is
-    torch.distributed's all_reduce, which is also what the CPU (gloo) tests can run.  The id travels over the existing process
-    group, whatever its backend."""
+    """One RCCL communicator per process group, driven through the C ABI (include/agan.h: agan_comm_* / agan_allreduce_bucket): each
+    bucket goes out as reduce-scatter + all-gather on the communicator's stream.  Opt-in (AGAN_RCCL_DIRECT=1); the default exchange
+    is torch.distributed's all_reduce, which is also what the CPU (gloo) tests can run.  The id travels over the existing process
+    group, whatever its backend.  PARITY UNPINNED across ranks: no multi-GPU box has run it yet (one-rank identity test and the
+    host-side chunk arithmetic test only) -- DESIGN.md section 6."""
 
-    _shared: dict = {}
+    _shared: dict = {}          # keyed by the group OBJECT (kept alive by the key: no id() reuse after garbage collection)
 
     def __init__(self, group=None):
         import ctypes
@@ -74,7 +93,9 @@ class DirectRccl:
             L.call("agan_comm_unique_id", buf)
             ident[0] = bytes(buf.raw)
         if world > 1:
-            dist.broadcast_object_list(ident, src=0, group=group)
+            # `src` of broadcast_object_list is a GLOBAL rank: group rank 0 of a subgroup need not be global rank 0
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(ident, src=src, group=group)
         self._id = ctypes.create_string_buffer(ident[0], L.COMM_ID_BYTES)
         self.comm = ctypes.c_void_p()
         L.call("agan_comm_init", ctypes.byref(self.comm), rank, world, self._id)
@@ -84,10 +105,21 @@ class DirectRccl:
 
     @classmethod
     def get(cls, group=None):
-        key = id(group)
-        if key not in cls._shared:
-            cls._shared[key] = cls(group)
-        return cls._shared[key]
+        if group not in cls._shared:
+            if not cls._shared:
+                import atexit
+                atexit.register(cls.close_all)          # communicators are destroyed before the interpreter tears the library down
+            cls._shared[group] = cls(group)
+        return cls._shared[group]
+
+    @classmethod
+    def close_all(cls) -> None:
+        for c in list(cls._shared.values()):
+            try:
+                c.close()
+            except Exception:      # interpreter shutdown: the library may already be gone
+                pass
+        cls._shared.clear()
 
     def all_reduce_(self, chunk: torch.Tensor, stream: torch.cuda.Stream) -> None:
         import ctypes
@@ -95,6 +127,7 @@ class DirectRccl:
 
     def close(self) -> None:
         if self.comm:
+            torch.cuda.synchronize()
             self.L.call("agan_comm_destroy", self.comm)
             self.comm = None
 
@@ -153,6 +186,8 @@ class GradBuckets:
     def _launch(self, b: int) -> None:
         s, e = self.bounds[b]
         self.opt._rebind(self.members[b])      # only this bucket's parameters: the others may still be mid-backward
+        for i in self.members[b]:              # from here to zero_grad() no backward kernel may write into this bucket (functional._grad_out)
+            self.opt.params[i]._agan_grad_dst.locked = True
         chunk = self.opt.grad[s:e]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())

@@ -12,8 +12,9 @@ class SentenceLoss:
         self.gamma3, self.slambda = gamma3, slambda
 
     def get_loss(self, cnn_code, rnn_code, labels, class_ids, eps=1e-8):
-        """cnn_code, rnn_code [B,nef]; labels [B] (= arange); class_ids array or None -> scalar loss."""
+        """cnn_code, rnn_code [B,nef]; labels [B] int64 CE targets (sentence_loss.py:46-47; arange in train.py:104);
+        class_ids array or None -> scalar loss."""
         if cnn_code.dim() != 2 or cnn_code.shape[0] < 2:
             # the reference's squeeze() (sentence_loss.py:41) breaks at B == 1 as well
             raise ValueError("SentenceLoss needs [B, nef] codes with B >= 2")
-        return HF.sentence_loss(cnn_code, rnn_code, class_ids, self.gamma3, self.slambda, eps)
+        return HF.sentence_loss(cnn_code, rnn_code, class_ids, self.gamma3, self.slambda, eps, labels)

@@ -22,20 +22,19 @@ class WordsLoss:
         return (w12 / (torch.norm(x1, 2, dim) * torch.norm(x2, 2, dim)).clamp(min=eps)).squeeze()
 
     def get_loss(self, img_features, words_emb, labels, cap_lens, class_ids):
-        """img_features [B,nef,17,17], words_emb [B,nef,T], labels [B] (= arange, as train.py:104 builds them),
-        cap_lens [B], class_ids [B] array or None -> (loss, [attention map [1,L_i,17,17] per caption])."""
+        """img_features [B,nef,17,17], words_emb [B,nef,T], labels [B] int64 (the CE targets of words_loss.py:98-99; train.py:104
+        builds arange, which `_make_match_labels` tags so the kernel's built-in default is used without a copy; any other vector
+        is honoured as given), cap_lens [B], class_ids [B] array or None -> (loss, [attention map [1,L_i,17,17] per caption])."""
         b = img_features.shape[0]
-        if labels is not None and labels.numel() != b:
-            raise ValueError("labels must have one entry per sample")
         ih, iw = img_features.shape[2], img_features.shape[3]
         if isinstance(cap_lens, torch.Tensor) and cap_lens.is_cuda:
             # lengths already on the device (HIP-graph capture / no host sync): the per-caption list cannot be cut without
             # reading the lengths back, so the maps come back as one zero-padded tensor [B, T, ih, iw]
             loss, maps, _ = HF.words_loss(img_features, words_emb, cap_lens.to(torch.int64), class_ids, self.gamma1, self.gamma2,
-                                          self.gamma3, self.wlambda)
+                                          self.gamma3, self.wlambda, labels)
             return (loss, maps.view(b, -1, ih, iw))
         lens = [int(v) for v in (cap_lens.tolist() if hasattr(cap_lens, "tolist") else cap_lens)]
         loss, maps, _ = HF.words_loss(img_features, words_emb, lens, class_ids, self.gamma1, self.gamma2, self.gamma3,
-                                      self.wlambda)
+                                      self.wlambda, labels)
         att_maps = [maps[i:i + 1, :lens[i]].reshape(1, lens[i], ih, iw) for i in range(b)]
         return (loss, att_maps)

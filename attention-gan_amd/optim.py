@@ -61,7 +61,7 @@ class FlatAdam:
         branch-free and only decays its moments)."""
         for p in self.params:
             p.grad = None
-            p._agan_grad_dst.written = False
+            p._agan_grad_dst.reset()
 
     def _rebind(self, indices=None) -> int:
         """Make p.grad the view into the flat buffer (for all parameters, or the given indices); gradients that landed
@@ -76,15 +76,29 @@ class FlatAdam:
                 continue
             view = self.grad[o:o + p.numel()].view(p.shape)
             if g is not None:
-                if p._agan_grad_dst.written:
-                    # A backward kernel wrote (and possibly accumulated further uses into) the slice directly: the slice is the
-                    # truth.  A foreign p.grad here is a clone autograd made of the FIRST contribution (it clones instead of
-                    # adopting the view when something else still references it) -- copying it back would drop every later
-                    # in-kernel accumulation, so it is discarded.
-                    pass
-                else:
+                dst = p._agan_grad_dst
+                if not dst.written:
+                    view.copy_(g)             # no kernel wrote the slice: a stock autograd gradient
+                    copies += 1
+                elif HF.wgrad_side_stream_enabled():
+                    # the kernel wrote the slice on a side stream autograd knows nothing about: its copy may have been taken too early
+                    raise RuntimeError("FlatAdam: autograd copied a gradient that was written on the weight-gradient side stream")
+                elif dst.edges <= 1:
+                    # ONE kernel contribution, and autograd holds a tensor of its own: either a clone of that contribution (it clones
+                    # instead of adopting the view when something else still references it) or its sum with stock autograd edges
+                    # of the same parameter (a tied weight, an op without a flat destination).  In both cases autograd's tensor is
+                    # the complete gradient.
                     view.copy_(g)
                     copies += 1
+                else:
+                    # Several kernel contributions accumulated in the slice.  A clone autograd took once every edge had arrived
+                    # equals the slice and is dropped; anything else is a stock autograd edge summed with only PART of the kernel
+                    # contributions, which cannot be reconstructed -- refuse rather than train on a wrong gradient.
+                    if torch.cuda.is_available() and p.is_cuda and torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("FlatAdam: autograd replaced a gradient with several in-kernel contributions during graph capture")
+                    if g.shape != view.shape or not torch.equal(g, view):
+                        raise RuntimeError("FlatAdam: a parameter received several in-kernel gradient contributions AND a stock autograd "
+                                           "gradient in one backward (tied weight?): unsupported, the sum cannot be recovered")
             elif not p._agan_grad_dst.written:
                 view.zero_()                  # no gradient reached this parameter in this backward
             p.grad = view

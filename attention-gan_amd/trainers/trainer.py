@@ -12,7 +12,7 @@ from torch import Tensor
 from torch.nn import Module
 
 from ..backend import functional as HF
-from ..dataparallel import GradBuckets, broadcast_module_, rank_of, sync_buffers_, world_size
+from ..dataparallel import GradBuckets, averaged_buffers, broadcast_module_, rank_of, world_size
 from ..losses.disc_loss import NonSaturatingDiscLoss
 from ..losses.gen_loss import NonSaturatingGenLoss
 from ..losses.KL_loss import KL_loss
@@ -32,7 +32,9 @@ class ModelTrainer:
         pass
 
     def _make_match_labels(self, batch_size: int) -> Tensor:
-        return torch.arange(batch_size, dtype=torch.int64, device=_device())
+        labels = torch.arange(batch_size, dtype=torch.int64, device=_device())
+        labels._agan_arange = batch_size          # lets the DAMSM losses use the kernels' built-in arange targets (no copy, no readback)
+        return labels
 
     def _count_parameters(self, model: Module):
         n = sum(p.numel() for p in model.parameters() if p.requires_grad)
@@ -117,6 +119,10 @@ class GanTrainStep(ModelTrainer):
         self.rank = rank_of(group)
         self.rng = torch.Generator(device=dev0)
         self.rng.manual_seed(int(seed) * 1000003 + self.rank)
+        # sampling (generate_images) draws from a generator of its own: looking at samples mid-training must not shift the
+        # training noise stream
+        self.sample_rng = torch.Generator(device=dev0)
+        self.sample_rng.manual_seed(int(seed) * 1000003 + 500009 + self.rank)
         self.g_opt = FlatAdam(self.G.parameters(), lr=gen_lr, betas=(0.5, 0.999))
         self.d_opts = [FlatAdam(d.parameters(), lr=disc_lr, betas=(0.5, 0.999)) for d in self.Ds]
         self.g_buckets = GradBuckets(self.g_opt, bucket_bytes, group)
@@ -278,14 +284,23 @@ class GanTrainStep(ModelTrainer):
         return GraphedStep(graph, out)
 
     # -- checkpoint / resume (the reference only saves, and its four `Adam` objects share one Adam.pkl) --
-    def state_dict(self) -> Dict:
-        """Under torch.distributed the BatchNorm running statistics are per replica (local batches, as in the reference's
-        single-process BN); the checkpoint holds their MEAN over the ranks (sync_buffers_), so every rank writes the same file."""
-        if world_size(self.group) > 1:
-            for m in [self.G] + self.Ds:
-                sync_buffers_(m, self.group)
-        return {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
-                "g_optim": self.g_opt.state_dict(), "d_optims": [o.state_dict() for o in self.d_opts]}
+    def state_dict(self, all_ranks: bool = True) -> Dict:
+        """Checkpoint of the whole step: weights, BatchNorm buffers, the four optimisers and the noise generators' states (so a
+        resumed run continues the z / eps sequence instead of replaying it from the seed).
+
+        Under torch.distributed the BatchNorm running statistics are per replica (local batches, as in the reference's
+        single-process BN).  With `all_ranks=True` (default) the checkpoint holds their MEAN over the ranks, so every rank
+        writes the same file -- this is a COLLECTIVE: every rank of the group must call state_dict(), a lone
+        `if rank == 0: save(step.state_dict())` would hang.  For that pattern pass `all_ranks=False`: no communication, the
+        calling rank's own statistics are saved.  The live buffers are never modified either way."""
+        sd = {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
+              "g_optim": self.g_opt.state_dict(), "d_optims": [o.state_dict() for o in self.d_opts],
+              "rng": self.rng.get_state(), "sample_rng": self.sample_rng.get_state()}
+        if all_ranks and world_size(self.group) > 1:
+            for m, msd in zip([self.G] + self.Ds, [sd["generator"]] + sd["discriminators"]):
+                for k, v in averaged_buffers(m, self.group).items():
+                    msd[k] = v
+        return sd
 
     def load_state_dict(self, sd: Dict) -> None:
         self.G.load_state_dict(sd["generator"])
@@ -293,6 +308,10 @@ class GanTrainStep(ModelTrainer):
         for d, o, ds, os_ in zip(self.Ds, self.d_opts, sd["discriminators"], sd["d_optims"]):
             d.load_state_dict(ds)
             o.load_state_dict(os_)
+        # noise streams (checkpoints written before these were saved simply restart them from the seed)
+        for key, gen in (("rng", self.rng), ("sample_rng", self.sample_rng)):
+            if sd.get(key) is not None:
+                gen.set_state(sd[key].cpu())
 
     @torch.no_grad()
     def generate_images(self, word_embs: Tensor, sent_embs: Tensor, lengths, noise: Optional[Tensor] = None) -> List[Tensor]:
@@ -303,8 +322,8 @@ class GanTrainStep(ModelTrainer):
         try:
             b = word_embs.shape[0]
             if noise is None:
-                noise = torch.randn(b, self.G.z_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
-            eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.rng)
+                noise = torch.randn(b, self.G.z_dim, dtype=torch.float32, device=word_embs.device, generator=self.sample_rng)
+            eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.sample_rng)
             fakes, _, _, _ = self.G(noise, sent_embs, word_embs, self._make_mask(lengths, word_embs.shape[2]), eps)
             return self._denormalise_multiple(fakes)
         finally:
@@ -331,8 +350,11 @@ class DAMSMTrainStep(ModelTrainer):
                  gamma2: float = 5.0, gamma3: float = 10.0, wlambda: float = 5.0, slambda: float = 5.0):
         super().__init__()
         self.rnn, self.cnn, self.clip = rnn, cnn, rnn_grad_clip
+        # ONE Adam over the RNN and the image encoder's trainable heads (pretrain_damsm.py:69-73), as one fused launch on a flat
+        # buffer; the RNN's parameters come first so that clip_grad_norm_ (:133) sees them as one contiguous slice
         params = list(rnn.parameters()) + [p for p in cnn.parameters() if p.requires_grad]
-        self.optim = torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999))
+        self.optim = FlatAdam(params, lr=lr, betas=(0.5, 0.999))
+        self._rnn_count = sum(1 for p in rnn.parameters() if p.requires_grad)
         dev = next(rnn.parameters()).device
         self.words_loss = WordsLoss(dev, gamma1, gamma2, gamma3, wlambda)
         self.sent_loss = SentenceLoss(dev, gamma3, slambda)
@@ -348,7 +370,8 @@ class DAMSMTrainStep(ModelTrainer):
         sloss = self.sent_loss.get_loss(sent_code, sent_embs, labels, class_ids)
         loss = wloss + sloss
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.rnn.parameters(), self.clip)
+        self.optim.join_and_rebind()                       # every p.grad is now its slice of the flat gradient buffer
+        torch.nn.utils.clip_grad_norm_(self.rnn.parameters(), self.clip)       # scales those slices in place (pretrain_damsm.py:133)
         self.optim.step()
         self.loss_history.append(loss.detach())
         return {"loss": loss.detach(), "w_loss": wloss.detach(), "s_loss": sloss.detach()}

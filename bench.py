@@ -221,13 +221,17 @@ def cpu_baseline(batch, repeats=3):
                       f"({', '.join(f'{t:.1f}' for t in times)} s)"}
 
 
-def side_measurements(args, dev, HF, LIB, step, words, sent, reals, n=8):
+def side_measurements(args, dev, HF, LIB, step, words, sent, reals):
     """Short eager measurements reported BESIDE the headline, never inside it or its roofline:
     random caption lengths 2..10 (the headline uses full-length captions), the other arithmetic modes of the conv engine, and the
     end-to-end step with the Inception-v3-shaped trunk (stock MIOpen convs, random weights) as the DAMSM image encoder and the
     bi-LSTM text encoder run on the device every step."""
+    # the SAME step and warm-up counts as the headline: a `--precision X` headline and the `precision_X` variant of another run are
+    # then the same measurement (8-step variants read 6 % low in round 2: clocks and allocator pools had not settled)
+    n, w = args.steps, max(args.warmup, 2)
+
     def rate(fn):
-        for _ in range(2):
+        for _ in range(w):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -235,7 +239,7 @@ def side_measurements(args, dev, HF, LIB, step, words, sent, reals, n=8):
             fn()
         torch.cuda.synchronize()
         return round(args.batch * n / (time.perf_counter() - t0), 1)
-    out = {"note": f"{n} eager steps each after 2 warm-up steps, same batch; images/s"}
+    out = {"note": f"{n} eager steps each after {w} warm-up steps (the headline's counts), same batch; images/s"}
     B = args.batch
     g = torch.Generator().manual_seed(99)
     lens_r = torch.randint(2, T + 1, (B,), generator=g)

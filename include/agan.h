@@ -217,7 +217,9 @@ int agan_func_attention_fwd(const float* query, const float* context, float gamm
 int agan_func_attention_bwd(const float* query, const float* context, const float* dwctx, const float* dattn, float gamma1,
                             float scale, float* dquery, float* dcontext, int B, int D, int L, int S, void* stream);
 size_t agan_words_loss_save_elems(int B, int D, int T, int S);
-int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids,
+/* labels [B] int64: the CE targets of words_loss.py:98-99 / sentence_loss.py:46-47 (NULL = arange(B), what train.py:104 builds;
+ * a label outside [0,B) makes the loss NaN).  class_ids [B] int64 or NULL: same-class pairs masked to -inf. */
+int agan_words_loss_fwd(const float* feat, const float* wemb, const int64_t* lens, const int64_t* class_ids, const int64_t* labels,
                         float gamma1, float gamma2, float gamma3, float lambda, float* loss, float* sim, float* attn_maps,
                         float* save, int B, int D, int T, int S, void* stream);
 /* backward: dfeat / dwemb are overwritten.  No atomics (bit-reproducible): each (image, caption) pair writes its contribution to a
@@ -226,7 +228,7 @@ size_t agan_words_loss_bwd_ws_bytes(int B, int D, int T, int S);
 int agan_words_loss_bwd(const float* feat, const float* wemb, const int64_t* lens, const float* save, const float* dloss,
                         float gamma1, float gamma2, float gamma3, float lambda, float* dfeat, float* dwemb,
                         int B, int D, int T, int S, void* ws, size_t ws_bytes, void* stream);
-int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, float gamma3, float lambda,
+int agan_sent_loss_fwd(const float* cnn_code, const float* rnn_code, const int64_t* class_ids, const int64_t* labels, float gamma3, float lambda,
                        float eps, float* loss, float* save /* 2*B*B + 2*B floats */, int B, int D, void* stream);
 int agan_sent_loss_bwd(const float* cnn_code, const float* rnn_code, const float* save, const float* dloss, float gamma3,
                        float lambda, float eps, float* dcnn, float* drnn, int B, int D, void* stream);
@@ -278,6 +280,9 @@ int agan_comm_unique_id(void* id);
 int agan_comm_init(void** comm, int rank, int world, const void* id);
 int agan_comm_destroy(void* comm);
 int agan_allreduce_bucket(void* comm, float* buf, size_t n, void* stream);
+/* the reduce-scatter / all-gather chunk of a bucket of n floats over `world` ranks (rank r owns elements [r*chunk, (r+1)*chunk));
+ * 0 = the bucket does not split into 16-byte aligned equal chunks and goes out as one library all-reduce.  Pure host arithmetic. */
+size_t agan_allreduce_chunk_elems(size_t n, int world);
 
 #ifdef __cplusplus
 }

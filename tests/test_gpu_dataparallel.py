@@ -57,6 +57,13 @@ def _worker(rank, world, port, q):
         draw = torch.randn(4, device=dev, generator=step.rng).cpu().numpy()          # the per-rank noise generator
         ckpt = step.state_dict()                                                    # averages BatchNorm statistics over the ranks
         bufs = {k: v.detach().cpu().numpy() for k, v in ckpt["generator"].items() if "running" in k}
+        import numpy as np
+        for k, v in G.state_dict().items():                                          # the checkpoint left the LIVE statistics alone
+            if "running" in k:
+                assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
+        if rank == 0:                                                               # the rank-0-only pattern: no collective, no hang
+            solo = step.state_dict(all_ranks=False)
+            assert all(np.array_equal(v.detach().cpu().numpy(), g_sd[k]) for k, v in solo["generator"].items() if "running" in k)
         # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
         q.put((rank, g_sd, d_sd, len(step.g_buckets.bounds), draw, bufs))
     finally:

@@ -646,6 +646,42 @@ def test_words_loss_mfma_pair_kernels_vs_oracle(D_, T_, side, dup):
     assert_close(wd.grad, wr.grad, RTOL, "dwemb")
 
 
+def test_damsm_losses_honour_labels():
+    """words_loss.py:98-99 / sentence_loss.py:46-47 feed whatever `labels` they are given to CrossEntropyLoss.  train.py:104 always
+    passes arange, but a permuted (or repeated) target vector must be scored as given: forward and backward vs the oracle, and
+    arange passed explicitly (pointer path) equals the tagged trainer labels (built-in default path) bit for bit."""
+    WL = importlib.import_module("attention-gan_amd.losses.words_loss").WordsLoss
+    SL = importlib.import_module("attention-gan_amd.losses.sentence_loss").SentenceLoss
+    TRN = importlib.import_module("attention-gan_amd.trainers.trainer")
+    gen = torch.Generator().manual_seed(77)
+    B = 6
+    feat, wemb = torch.randn(B, 64, 17, 17, generator=gen), torch.randn(B, 64, 10, generator=gen)
+    code, semb = torch.randn(B, 64, generator=gen), torch.randn(B, 64, generator=gen)
+    lens = [10, 3, 7, 1, 10, 5]
+    for labels in (torch.tensor([2, 0, 1, 5, 3, 4]), torch.tensor([0, 0, 3, 3, 1, 5])):
+        fr, wr, cr, sr = (t.clone().requires_grad_(True) for t in (feat, wemb, code, semb))
+        lw_r, _ = O.words_loss(fr, wr, labels, lens, None)
+        ls_r = O.sentence_loss(cr, sr, labels, None)
+        (lw_r + ls_r).backward()
+        fd, wd, cd, sd = (t.to(DEV).requires_grad_(True) for t in (feat, wemb, code, semb))
+        lw, _ = WL(torch.device(DEV)).get_loss(fd, wd, labels.to(DEV), lens, None)
+        ls = SL(torch.device(DEV)).get_loss(cd, sd, labels, None)          # host labels are accepted too
+        (lw + ls).backward()
+        assert_close(lw, lw_r, TOL.tight, "wloss with labels")
+        assert_close(ls, ls_r, TOL.tight, "sloss with labels")
+        for got, want, what in ((fd, fr, "dfeat"), (wd, wr, "dwemb"), (cd, cr, "dcode"), (sd, sr, "dsemb")):
+            assert_close(got.grad, want.grad, RTOL, what)
+    tagged = TRN.ModelTrainer()._make_match_labels(B)
+    assert getattr(tagged, "_agan_arange", None) == B
+    a, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), tagged, lens, None)
+    b, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.arange(B, device=DEV), lens, None)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.arange(B - 1, device=DEV), lens, None)
+    bad, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.tensor([0, 1, 2, 3, 4, B], device=DEV), lens, None)
+    assert torch.isnan(bad)          # a target outside [0, B): torch raises, the kernel poisons the loss
+
+
 def test_small_losses_vs_golden():
     KL = importlib.import_module("attention-gan_amd.losses.KL_loss").KL_loss
     g = load("a10_losses")

@@ -1,0 +1,89 @@
+"""Trajectory evidence for the arithmetic modes of the conv engine.
+
+A single step tells how close one evaluation is; a training run needs the modes to stay on the same TRAJECTORY while weights and
+activations move away from their initial statistics (the fp16 split's range scaling -- amax slots, weights x 2^11 -- is only
+exercised then).  STEPS consecutive train steps of BASELINE.json configs[2] (batch 24, changing synthetic batches, random caption
+lengths) run in f32 and in each other mode from the same initial weights and the same noise; at every logged step each loss
+of a mode must lie within a band of the f32 run's (fp32-grade modes: BAND_SPLIT; rounded 16-bit modes: BAND_ROUNDED) and be finite.
+The curves are written to gpurun_out/trajectory_<round>.txt (committed under profiles/).
+
+A GAN step is chaotic in the long run -- Adam's first steps are sign-like and a LeakyReLU kink can flip -- so the band is on the
+loss VALUES (statistics of the batch), not on weights, and the horizon is short.
+"""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+STEPS, EVERY = 40, 5
+LOSSES = ("d_loss0", "d_loss1", "d_loss2", "g_loss2", "w_loss", "s_loss", "kl", "g_total")
+BAND_SPLIT = 0.05          # bf16x6 / f16x3: relative to max(1, |f32 value|)
+BAND_ROUNDED = 0.25        # bf16 / f16 (8 / 11 significant bits per operand)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(bench, HF, LIB, mode, init):
+    HF.set_precision(LIB.PRECISIONS[mode])
+    try:
+        dev = torch.device("cuda", 0)
+        step = bench.build(dev, 24, HF)
+        if init is not None:
+            step.load_state_dict(init)
+        else:
+            init = {k: v for k, v in step.state_dict().items()}
+            import copy
+            init = copy.deepcopy(init)
+        g = torch.Generator().manual_seed(5)
+        curve = []
+        amax_seen = 0.0
+        for it in range(STEPS):
+            words, sent, _, reals = bench.synthetic_batch(dev, 24, seed=1000 + it % 7)
+            lens = torch.randint(2, 11, (24,), generator=g)
+            lens[0] = 10
+            noise = torch.randn(24, bench.Z, generator=g).to(dev)
+            eps = torch.randn(24, bench.COND, generator=g).to(dev)
+            out = step.step(words, sent, lens.to(dev), None, reals, noise, eps)
+            if it % EVERY == EVERY - 1 or it == 0:
+                curve.append((it + 1, {k: float(out[k]) for k in LOSSES}))
+        wmax = max(float(p.abs().max()) for p in step.G.parameters())
+        del step
+        torch.cuda.empty_cache()
+        return init, curve, wmax
+    finally:
+        HF.set_precision(LIB.PREC_F32)
+
+
+def test_modes_stay_on_the_f32_trajectory():
+    sys.path.insert(0, ROOT)
+    import bench
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    LIB = importlib.import_module("attention-gan_amd.backend.lib")
+    init, ref, wmax_ref = _run(bench, HF, LIB, "f32", None)
+    lines = [f"{STEPS} train steps of BASELINE configs[2] (batch 24) per mode, same initial weights, batches and noise; losses at the logged steps",
+             "f32    " + "  ".join(f"step {s}: " + " ".join(f"{k}={v[k]:.4f}" for k in LOSSES) for s, v in ref), f"f32    max |G weight| {wmax_ref:.4f}"]
+    bad = []
+    for mode, band in (("bf16x6", BAND_SPLIT), ("f16x3", BAND_SPLIT), ("f16", BAND_ROUNDED), ("bf16", BAND_ROUNDED)):
+        _, cur, wmax = _run(bench, HF, LIB, mode, init)
+        worst = 0.0
+        for (s, v), (s0, v0) in zip(cur, ref):
+            assert s == s0
+            for k in LOSSES:
+                if not (v[k] == v[k] and abs(v[k]) < 1e6):
+                    bad.append(f"{mode} step {s} {k} not finite: {v[k]}")
+                    continue
+                d = abs(v[k] - v0[k]) / max(1.0, abs(v0[k]))
+                worst = max(worst, d)
+                if d > band:
+                    bad.append(f"{mode} step {s} {k}: {v[k]:.4f} vs f32 {v0[k]:.4f} (rel {d:.3f} > {band})")
+        lines.append(f"{mode:6s} " + "  ".join(f"step {s}: " + " ".join(f"{k}={v[k]:.4f}" for k in LOSSES) for s, v in cur))
+        lines.append(f"{mode:6s} max |G weight| {wmax:.4f}; worst loss deviation from the f32 run {worst:.4f} (band {band})")
+    report = "\n".join(lines)
+    print("\n" + report)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "trajectory_r03.txt"), "w") as f:
+        f.write(report + "\n")
+    assert not bad, "\n".join(bad)

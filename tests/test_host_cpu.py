@@ -307,3 +307,79 @@ def test_flat_buffer_epochs_are_per_buffer_and_survive_recycling():
         assert HF._flat_range(b.data_ptr()) is None
     finally:
         HF._FLAT_RANGES[:] = saved
+
+
+def test_rebind_keeps_autograd_sums_and_refuses_the_unrecoverable_case():
+    """FlatAdam._rebind policy for a slice a backward KERNEL wrote while autograd ended up holding a tensor of its own
+    (ADVICE r2): one kernel contribution -> autograd's tensor (a clone, or its sum with a stock edge of a tied weight) is the whole
+    gradient and is copied in; several kernel contributions -> a clone equals the slice and is dropped, anything else raises."""
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    lin = torch.nn.Linear(4, 3)
+    opt = OPT.FlatAdam(lin.parameters())
+    w = opt.params[0]
+    dst = w._agan_grad_dst
+    # -- one kernel edge + a stock edge summed by autograd (foreign tensor = kernel part + stock part)
+    opt.zero_grad()
+    buf, acc, handed = HF._grad_out(dst, w.shape, w)
+    assert acc == 0 and handed.data_ptr() == opt.grad.data_ptr() + 4 * opt.offsets[0] and dst.edges == 1
+    buf.fill_(1.0)                                              # "the kernel" writes the slice
+    w.grad = handed + 2.0                                       # autograd's out-of-place sum with a stock edge
+    assert opt._rebind([0]) == 1
+    assert torch.equal(opt.grad[:w.numel()], torch.full((w.numel(),), 3.0)) and w.grad.data_ptr() == opt.grad.data_ptr()
+    # -- two kernel edges, autograd cloned after both: equal to the slice -> dropped silently
+    opt.zero_grad()
+    buf, _, handed = HF._grad_out(dst, w.shape, w)
+    buf.fill_(1.0)
+    buf2, acc2, handed2 = HF._grad_out(dst, w.shape, w)
+    assert acc2 == 1 and handed2 is None and dst.edges == 2
+    buf2.add_(4.0)                                              # in-kernel accumulation of the second use
+    w.grad = handed.clone()
+    assert opt._rebind([0]) == 0 and torch.equal(opt.grad[:w.numel()], torch.full((w.numel(),), 5.0))
+    # -- two kernel edges AND a stock edge summed with only the first: cannot be reconstructed -> refuse
+    opt.zero_grad()
+    buf, _, handed = HF._grad_out(dst, w.shape, w)
+    buf.fill_(1.0)
+    foreign = handed + 2.0
+    HF._grad_out(dst, w.shape, w)[0].add_(4.0)
+    w.grad = foreign
+    with pytest.raises(RuntimeError, match="several in-kernel"):
+        opt._rebind([0])
+
+
+def test_bucket_lock_refuses_a_second_backward_into_an_exchanged_bucket():
+    """Once a bucket has been handed to the gradient exchange no backward kernel may write into it until zero_grad()
+    (without the old zero-fill a second backward would add into a bucket whose all-reduce is in flight)."""
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    LIB = importlib.import_module("attention-gan_amd.backend.lib")
+    lin = torch.nn.Linear(4, 3)
+    opt = OPT.FlatAdam(lin.parameters())
+    dst = opt.params[0]._agan_grad_dst
+    opt.zero_grad()
+    HF._grad_out(dst, opt.params[0].shape, opt.params[0])
+    dst.locked = True                                           # what GradBuckets._launch does for the bucket's members
+    with pytest.raises(LIB.AganError, match="already being all-reduced"):
+        HF._grad_out(dst, opt.params[0].shape, opt.params[0])
+    opt.zero_grad()
+    assert not dst.locked and dst.edges == 0
+    HF._grad_out(dst, opt.params[0].shape, opt.params[0])
+
+
+def test_direct_rccl_chunk_arithmetic():
+    """agan_allreduce_chunk_elems (pure host code of csrc/comm.hip): the reduce-scatter / all-gather split of a bucket -- equal,
+    16-byte aligned chunks that tile the bucket exactly (rank r owns [r*chunk, (r+1)*chunk)), or 0 = library all-reduce."""
+    lib = importlib.import_module("attention-gan_amd.backend.lib").load()
+    for world in (1, 2, 4, 8):
+        for n in (4, 8, 32, 1000, 1024, 4096 + 4, 16 << 20, (16 << 20) + 4, 7_084_592, 68_310_785, 12345):
+            chunk = lib.agan_allreduce_chunk_elems(n, world)
+            if n % world == 0 and (n // world) % 4 == 0:
+                assert chunk == n // world and chunk * world == n and (chunk * 4) % 16 == 0
+                offs = [r * chunk for r in range(world)]
+                assert offs[-1] + chunk == n and all((o * 4) % 16 == 0 for o in offs)
+            else:
+                assert chunk == 0
+    assert lib.agan_allreduce_chunk_elems(0, 8) == 0 and lib.agan_allreduce_chunk_elems(64, 0) == 0
+    # the buckets GradBuckets cuts from a flat buffer are multiples of 4 elements (16-byte aligned parameters)
+    mods = torch.nn.Sequential(*[torch.nn.Linear(33, 17) for _ in range(5)])
+    opt = OPT.FlatAdam(mods.parameters())
+    bk = DP.GradBuckets(opt, bucket_bytes=3000)
+    assert all((e - s) % 4 == 0 and s % 4 == 0 for s, e in bk.bounds)
