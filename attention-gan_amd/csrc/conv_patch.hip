@@ -153,6 +153,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     constexpr int U0 = SPS - NI;                                  // first k-step that carries a staging item
     static_assert(U0 >= 0, "stage too short for its staging items");
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
+    // depth of the weight-fragment register ring = how many k-steps ahead a fragment is fetched from L2.  A one-plane k-step is
+    // only TM MFMAs (128 cycles): two steps ahead (the depth the split modes use, whose k-steps are 3-6x longer) left every k-step
+    // waiting ~300 cycles for its L2 hit -- MFMA-busy 11-18 % in round 2.  The depth divides the k-steps per stage (8 or 18), so
+    // slot indices stay compile-time constants across stages.
+#ifndef AGAN_PATCH_WD1
+#define AGAN_PATCH_WD1 0
+#endif
+    constexpr int WD = (NPL == 1 && HS == 2) ? (AGAN_PATCH_WD1 ? AGAN_PATCH_WD1 : (NT == 9 ? 6 : 4)) : 2;
+    static_assert(NPL != 1 || SPS % WD == 0, "ring depth must divide the k-steps per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char patch2[];
     const int buf_bytes = NPL * plane_bytes;
 
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     const unsigned wstep = (unsigned)(NPL * g.Nld * 32);
     // k-step of the packed weights for (stage, tap, 16-channel sub-step): taps are 2 k-steps apart, the sub-step is the low bit
     auto qof = [&](const Stage& S, int tap, int hh) { return S.wq + tap * 2 + (HS == 2 ? hh : 0); };
-    u32x4 wf[2][NPL];
+    u32x4 wf[WD][NPL];
     auto load_w = [&](int slot, int q) {
         const unsigned so = (unsigned)min(q, pp.nsteps - 1) * wstep;
 #pragma unroll
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
 
     if (stage_beg < stage_end) {
         Stage cs = stage_of(stage_beg);
-        load_w(0, qof(cs, 0, 0));
-        load_w(1, qof(cs, 1 / HS, 1 % HS));
+#pragma unroll
+        for (int d = 0; d < WD; ++d) load_w(d, qof(cs, d / HS, d % HS));       // (WD <= k-steps per stage)
         load_patch(cs);
 #pragma unroll
         for (int i = 0; i < NI; ++i) store_item(i, patch2 + (stage_beg & 1) * buf_bytes);
@@ -307,12 +316,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
             for (int u = 0; u < SPS; ++u) {
                 u32x4 w[NPL];
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) w[p] = wf[u & 1][p];
-                {   // weights two k-steps ahead (possibly in the next stage; past the last stage: a harmless repeat)
-                    const int u2 = u + 2;
+                for (int p = 0; p < NPL; ++p) w[p] = wf[u % WD][p];
+                {   // weights WD k-steps ahead (possibly in the next stage; past the last stage: a harmless repeat)
+                    const int u2 = u + WD;
 #if !defined(AGAN_PATCH_ABLATE) || AGAN_PATCH_ABLATE != 3
-                    if (u2 < SPS) load_w(u & 1, qof(cs, u2 / HS, u2 % HS));
-                    else load_w(u & 1, qof(ns, (u2 - SPS) / HS, (u2 - SPS) % HS));
+                    if (u2 < SPS) load_w(u % WD, qof(cs, u2 / HS, u2 % HS));
+                    else load_w(u % WD, qof(ns, (u2 - SPS) / HS, (u2 - SPS) % HS));
 #endif
                 }
 #if defined(AGAN_PATCH_ABLATE) && AGAN_PATCH_ABLATE == 5
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
                 if (u >= U0 && more) store_item(u - U0, nxt);      // next stage's patch, one item per k-step, behind the MFMAs
 #endif
             }
-            if (SPS & 1) {        // an odd number of k-steps per stage flips the parity of the two-slot weight ring: swap it back
+            if (WD == 2 && (SPS & 1)) {        // an odd number of k-steps per stage flips the parity of the two-slot weight ring: swap it back
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) { const u32x4 tmp = wf[0][p]; wf[0][p] = wf[1][p]; wf[1][p] = tmp; }
             }

@@ -127,6 +127,9 @@ class GanTrainStep(ModelTrainer):
         self.d_opts = [FlatAdam(d.parameters(), lr=disc_lr, betas=(0.5, 0.999)) for d in self.Ds]
         self.g_buckets = GradBuckets(self.g_opt, bucket_bytes, group)
         self.d_buckets = [GradBuckets(o, bucket_bytes, group) for o in self.d_opts]
+        # issue order of the three independent discriminator updates: LARGEST first (Disc256: 273 MB of gradients, the long pole of
+        # the exchange), so that its buckets travel while the smaller discriminators still compute.  Results do not depend on it.
+        self.d_order = sorted(range(len(self.Ds)), key=lambda i: -self.d_opts[i].numel)
         dev = next(self.G.parameters()).device
         self.words_loss = WordsLoss(dev, gamma1, gamma2, gamma3, wlambda)
         self.sent_loss = SentenceLoss(dev, gamma3, slambda)
@@ -183,7 +186,8 @@ class GanTrainStep(ModelTrainer):
         if streams is not None:
             for st in streams:                      # discriminator weight gradients run on the (otherwise idle) main stream
                 HF.set_side_stream_for(st, main)
-        for i, (d, opt, bk) in enumerate(zip(self.Ds, self.d_opts, self.d_buckets)):
+        for i in self.d_order:
+            d, opt, bk = self.Ds[i], self.d_opts[i], self.d_buckets[i]
             if streams is not None:
                 streams[i].wait_stream(main)
                 ctx = torch.cuda.stream(streams[i])

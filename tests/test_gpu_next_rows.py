@@ -319,7 +319,8 @@ def test_config1_stage1_batch64_bf16():
 # (gf, df, emb, z = cond) -> bounds (image max-rel, image L2, D512 output abs, worst generator-gradient L2 vs the f32 mode)
 _CONFIG4_WIDTHS = {
     "toy-gf8-df8": ((8, 8, 32, 16), (2e-1, 5e-2, 5e-2, 5e-1)),
-    "metric-gf32-df64": ((32, 64, 256, 100), (2e-1, 5e-2, 5e-2, 5e-1)),
+    # observed on MI355X (round 3): image 1.7e-2 max / 2.1e-3 L2, Disc512 output 9.0e-4, gradients 1.7e-1
+    "metric-gf32-df64": ((32, 64, 256, 100), (5e-2, 1e-2, 5e-3, 3.5e-1)),
 }
 
 
@@ -618,7 +619,7 @@ def test_paired_discriminator_pass_at_metric_size():
         finally:
             O.LEAKY_MASKS = O.LEAKY_STATS = None
         # the imposed branches may differ from the oracle's own x >= 0 only on a few elements within rounding of zero
-        print(O.check_leaky_stats(stats, 8, 1e-5, f"kink sync {form} {str(dt)[6:]}"))
+        print(O.check_leaky_stats(stats, 1e-5, 1e-5, f"kink sync {form} {str(dt)[6:]}"))      # observed: 20 of 1e8, |x| <= 1.1e-6 max|x|
         return loss.detach(), dict(zip(keys, torch.autograd.grad(loss, [p[k] for k in keys]))), p
     ref = {form: (oracle(torch.float32, form), oracle(torch.float64, form)) for form in queues}
     l32, _, p32 = ref["one-pass"][0]
