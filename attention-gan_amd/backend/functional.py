@@ -56,8 +56,74 @@ def _dev(t: Tensor, what: str) -> Tensor:
     if not t.is_cuda:
         raise L.AganError(f"{what}: tensor is on {t.device}; the AttnGAN HIP path runs on an MI355X only (no CPU fallback)")
     if t.dtype != torch.float32:
+        if t.dtype in _DT_OF:            # a 16-bit activation arriving at a kernel without typed storage: widen at the boundary
+            return t.float().contiguous()
         raise L.AganError(f"{what}: expected float32, got {t.dtype}")
     return t.contiguous()
+
+
+# ---- 16-bit activation storage (include/agan.h: AGAN_DT_*) ------------------------------------------------------------------
+# Off by default: every tensor in HBM is fp32 like the reference's.  set_activation_storage("bf16" | "f16") -- valid with
+# set_precision(PREC_BF16 / PREC_F16) -- lets conv outputs, BatchNorm inputs / outputs and their gradients live in the operand
+# type of the matrix cores: rounded ONCE when stored, loaded without conversion, half the bytes.  Kernels without typed storage
+# (attention, the <= 4-channel convs, losses) widen their inputs at the boundary (_dev).
+_DT_OF = {torch.bfloat16: L.DT_BF16, torch.float16: L.DT_F16}
+_TORCH_OF = {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16, L.DT_F16: torch.float16}
+_STORAGE = [L.DT_F32]
+
+
+def set_activation_storage(kind) -> None:
+    dt = {None: L.DT_F32, "f32": L.DT_F32, "bf16": L.DT_BF16, "f16": L.DT_F16}[kind]
+    _STORAGE[0] = dt
+
+
+def get_activation_storage() -> int:
+    """the storage type 16-bit-capable kernels produce right now: AGAN_DT_F32 unless the precision mode matches the request"""
+    dt = _STORAGE[0]
+    if dt == L.DT_BF16 and _PRECISION[0] == L.PREC_BF16:
+        return dt
+    if dt == L.DT_F16 and _PRECISION[0] == L.PREC_F16:
+        return dt
+    return L.DT_F32
+
+
+def _dt(t: Tensor) -> int:
+    return L.DT_F32 if t.dtype == torch.float32 else _DT_OF[t.dtype]
+
+
+def _act(t: Tensor, what: str) -> Tensor:
+    """an activation tensor for a kernel WITH typed storage: fp32 or a 16-bit type, contiguous, on the device"""
+    if not t.is_cuda:
+        raise L.AganError(f"{what}: tensor is on {t.device}; the AttnGAN HIP path runs on an MI355X only (no CPU fallback)")
+    if t.dtype != torch.float32 and t.dtype not in _DT_OF:
+        raise L.AganError(f"{what}: expected float32 / bfloat16 / float16, got {t.dtype}")
+    return t.contiguous()
+
+
+_DT_SUPPORT: dict = {}
+
+
+def _gather_types(g: "L.ConvGeom", pe: int, x: Tensor, want_out: int):
+    """-> (x, storage type of the output) for a gather of geometry g in arithmetic mode pe: the 16-bit storage the caller would like
+    where the kernel for this geometry offers it (agan_conv_gather_dt_supported), else fp32 -- widening a 16-bit x when the layer
+    cannot read it as it stands (the deep 4x4 layers, whose rows are shorter than one 16-byte block)."""
+    def ok(xin, out):
+        if xin == L.DT_F32 and out == L.DT_F32:
+            return True
+        key = (g.B, g.Cin, g.IH, g.IW, g.Cout, g.OH, g.OW, g.R, g.S, g.OS, g.SY, g.DY, g.OY[0], g.OY[1], pe, xin, out)
+        hit = _DT_SUPPORT.get(key)
+        if hit is None:
+            hit = _DT_SUPPORT[key] = bool(L.load().agan_conv_gather_dt_supported(byref(g), pe, xin, out))
+        return hit
+    outs = [want_out, L.DT_F32] if want_out != L.DT_F32 else [L.DT_F32]
+    for out in outs:
+        if ok(_dt(x), out):
+            return x, out
+    x = x.float()
+    for out in outs:
+        if ok(L.DT_F32, out):
+            return x, out
+    return x, L.DT_F32
 
 
 def _ws(nbytes: int, like: Tensor) -> Tuple[Optional[Tensor], Optional[c_void_p]]:
@@ -385,10 +451,10 @@ def _gather(x: Tensor, wk: Tensor, bias: Optional[Tensor], g: L.ConvGeom, out: T
     kt = ktable(g, x.device)
     obs = _OBSERVER[0]
     if obs is not None:
-        obs.begin(kind, phase, g)
+        obs.begin(kind, phase, g, x.element_size(), out.element_size())
     out_amax = _amax_out(out) if prec != L.PREC_F32 else None       # the 16-bit kernels fold max|out| into a slot as they store
-    L.call("agan_conv_gather", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), prec, act, _p(lrelu_mask), wsp, nbytes,
-           _stream(), _p(in_amax), _p(out_amax))
+    L.call("agan_conv_gather_dt", _p(x), _p(wk), _p(bias), _p(out), byref(g), _p(kt), prec, act, _p(lrelu_mask), wsp, nbytes,
+           _stream(), _p(in_amax), _p(out_amax), _dt(x), _dt(out))
     if obs is not None:
         obs.end()
 
@@ -462,16 +528,17 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], kind: str, cache: Optional[dict], wdst, bdst, act: int = 0,
                 handoff_out: Optional[ActHandoff] = None, handoff_in: Optional[ActHandoff] = None):
-        x = _dev(x, "conv input")
+        x = _act(x, "conv input")
         w = _dev(weight.detach(), "conv weight")
         B, Cin, H, W = x.shape
         Cout, Cin_w, kh, kw = w.shape
         if Cin != Cin_w or kh != kw:
             raise L.AganError(f"conv: input has {Cin} channels, weight {tuple(w.shape)}")
         gf, pf, gd, pd, (OH, OW) = conv_geoms(kind, B, Cin, H, W, Cout, kh)
-        out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
-        b = _dev(bias.detach(), "conv bias") if bias is not None else None
         pe = effective_precision(gf)
+        x, odt = _gather_types(gf, pe, x, get_activation_storage())       # 16-bit activation storage where the layer offers it
+        out = torch.empty((B, Cout, OH, OW), dtype=_TORCH_OF[odt], device=x.device)
+        b = _dev(bias.detach(), "conv bias") if bias is not None else None
         xs = amax_of(x) if pe == L.PREC_F16X3 else None               # (kept for the weight gradient)
         _gather(x, packed_weight(w, pf, cache, pe), b, gf, out, kind, "fwd", act, None, pe, xs)
         ctx.x_scale = xs
@@ -489,12 +556,13 @@ class _ConvFn(Function):
     @once_differentiable
     def backward(ctx, dy: Tensor):
         x, w = ctx.saved_tensors[:2]
-        dy = _dev(dy, "conv grad")
+        dy = _act(dy, "conv grad")
         if ctx.act != L.ACT_NONE:
             if ctx.handoff_out is not None and ctx.handoff_out.masked:
                 ctx.handoff_out.masked = False          # the consumer's dgrad epilogue already applied LeakyReLU'(out)
             else:
-                out = ctx.saved_tensors[2]
+                out = _dev(ctx.saved_tensors[2], "conv output")
+                dy = _dev(dy, "conv grad")
                 dz = torch.empty_like(dy)
                 L.call("agan_act_bwd", _p(out), _p(dy), _p(dz), out.numel(), ctx.act, _stream())
                 dy = dz
@@ -523,21 +591,29 @@ class _ConvFn(Function):
                 kt = ktable(gf, x.device)
                 obs = _OBSERVER[0]
                 if obs is not None:
-                    obs.begin(ctx.kind, "wgrad", gf)
+                    obs.begin(ctx.kind, "wgrad", gf, x.element_size(), dy.element_size())
                 xs = None
                 if scaled_w:
                     xs = ctx.x_scale if ctx.x_scale is not None else amax_of(x)
-                L.call("agan_conv_wgrad", _p(x), _p(dy), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, pe_w, wacc, wsp, nbytes,
-                       _stream(), _p(xs), _p(dys if scaled_w else None))
+                xw, dyw = x, dy
+                if (xw.dtype != torch.float32 or dyw.dtype != torch.float32) and not lib.agan_conv_wgrad_dt_supported(
+                        byref(gf), pf, _PRECISION[0], _dt(xw), _dt(dyw)):
+                    xw, dyw = xw.float(), dyw.float()         # a weight gradient without typed storage: widen its operands
+                L.call("agan_conv_wgrad_dt", _p(xw), _p(dyw), _p(dwbuf), byref(gf), _p(kt), pf, kh, kw, pe_w, wacc, wsp, nbytes,
+                       _stream(), _p(xs), _p(dys if scaled_w else None), _dt(xw), _dt(dyw))
                 if obs is not None:
                     obs.end()
             if want_b:
                 dbbuf, bacc, db = _grad_out(ctx.bdst, (Cout,), x)
-                L.call("agan_bias_grad", _p(dy), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
+                L.call("agan_bias_grad", _p(_dev(dy, "conv grad")), _p(dbbuf), B, Cout, dy.shape[2] * dy.shape[3], bacc, _stream())
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            # dx takes x's storage type where the data-gradient kernel offers it (autograd wants the gradient in the input's dtype)
+            dyg, ddt = _gather_types(gd, pe_d, dy, _dt(x))
+            dx = torch.empty(x.shape, dtype=_TORCH_OF[ddt], device=x.device)
             mask = x if ctx.handoff_in is not None else None       # x is the producer's LeakyReLU output
-            _gather(dy, packed_weight(w, pd, ctx.cache, pe_d), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask, pe_d,
+            if mask is not None and mask.dtype != dx.dtype:
+                mask = mask.to(dx.dtype)
+            _gather(dyg, packed_weight(w, pd, ctx.cache, pe_d), None, gd, dx, ctx.kind, "dgrad", L.ACT_NONE, mask, pe_d,
                     dys if pe_d == L.PREC_F16X3 else None)
             if mask is not None:
                 ctx.handoff_in.masked = True
@@ -591,7 +667,7 @@ def bn_groups(groups: int):
 class _BnActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, act, eps, momentum, gdst, bdst, groups):
-        x = _dev(x, "bn input")
+        x = _act(x, "bn input")
         shape = x.shape
         B, C = shape[0], shape[1]
         HW = x.numel() // (B * C)
@@ -603,22 +679,31 @@ class _BnActFn(Function):
         g, b = _dev(gamma.detach(), "bn weight"), _dev(beta.detach(), "bn bias")
         lib = L.load()
         co = C // 2 if act == L.ACT_GLU else C
-        out = torch.empty((B, co) + tuple(shape[2:]), dtype=torch.float32, device=x.device)
-        res = _dev(residual, "bn residual") if residual is not None else None
+        # storage types (include/agan.h: agan_bn_*_dt): the output takes the activation storage in force (4-D tensors only); a 16-bit
+        # input is read as it stands when the output has the same type, else widened
+        odt = get_activation_storage() if HW > 1 else L.DT_F32
+        if x.dtype != torch.float32 and _dt(x) != odt:
+            x = x.float()
+        xdt = _dt(x)
+        out = torch.empty((B, co) + tuple(shape[2:]), dtype=_TORCH_OF[odt], device=x.device)
+        res = _act(residual, "bn residual") if residual is not None else None
+        if res is not None and res.dtype != out.dtype:
+            res = res.to(out.dtype)
         if training:
             mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
             nbytes = lib.agan_bn_train_fwd_ws_bytes(Bg, C, HW)
             ws, wsp = _ws(nbytes, x)
-            L.call("agan_bn_train_fwd", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
+            L.call("agan_bn_train_fwd_dt", _p(x), _p(g), _p(b), _p(res), _p(out), _p(mean), _p(invstd), _p(running_mean),
                    _p(running_var), _p(nbt), B, C, HW, float(eps), float(momentum), act, groups, wsp, nbytes, _stream(),
-                   _p(_amax_out(out)))
+                   _p(_amax_out(out)), xdt, odt)
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-            L.call("agan_bn_act_fwd", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream(),
-                   _p(_amax_out(out)))
+            L.call("agan_bn_act_fwd_dt", _p(x), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), B, C, HW, act, _stream(),
+                   _p(_amax_out(out)), xdt, odt)
         ctx.save_for_backward(x, g, b, mean, invstd)
+        ctx.odt = odt
         ctx.act, ctx.training, ctx.has_res, ctx.gdst, ctx.bdst, ctx.groups = act, training, residual is not None, gdst, bdst, groups
         return out
 
@@ -628,7 +713,9 @@ class _BnActFn(Function):
         if not ctx.training:
             raise L.AganError("BatchNorm backward in eval mode is not on the training path")
         x, g, b, mean, invstd = ctx.saved_tensors
-        dout = _dev(dout, "bn grad")
+        dout = _act(dout, "bn grad")
+        if _dt(dout) != ctx.odt:                     # (autograd delivers the output's dtype; a hand-made gradient may not)
+            dout = dout.to(_TORCH_OF[ctx.odt])
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         groups = ctx.groups
@@ -642,8 +729,8 @@ class _BnActFn(Function):
             raise L.AganError("BatchNorm weight/bias gradient destinations out of step")
         nbytes = L.load().agan_bn_act_bwd_ws_bytes(Bg, C, HW)
         ws, wsp = _ws(nbytes, x)
-        L.call("agan_bn_act_bwd", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
-               ctx.act, gacc, groups, wsp, nbytes, _stream(), _p(_amax_out(dx)))
+        L.call("agan_bn_act_bwd_dt", _p(x), _p(dout), _p(mean), _p(invstd), _p(g), _p(b), _p(dx), _p(dgbuf), _p(dbbuf), B, C, HW,
+               ctx.act, gacc, groups, wsp, nbytes, _stream(), _p(_amax_out(dx)), _dt(x), ctx.odt)
         dres = dout if ctx.has_res else None
         return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 

@@ -18,6 +18,7 @@ PRECISIONS = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": 
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_4x4S2, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128    # include/agan.h: AGAN_COMM_ID_BYTES
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # include/agan.h: AGAN_DT_* (storage type of an activation tensor)
 AMAX_SLOT = 256        # floats per amax slot (include/agan.h: AGAN_AMAX_SLOT)
 
 
@@ -53,6 +54,14 @@ _SIGNATURES = {
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),
     "agan_conv_gather": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P]),
+    "agan_conv_gather_dt": (c_int, [_P, _P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P, c_int, c_int]),
+    "agan_conv_gather_dt_supported": (c_int, [POINTER(ConvGeom), c_int, c_int, c_int]),
+    "agan_conv_wgrad_dt_supported": (c_int, [POINTER(ConvGeom), c_int, c_int, c_int, c_int]),
+    "agan_conv_wgrad_dt": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P, c_int, c_int]),
+    "agan_bn_stats_dt": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P, c_int]),
+    "agan_bn_act_fwd_dt": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int]),
+    "agan_bn_train_fwd_dt": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_size_t, _P, _P, c_int, c_int]),
+    "agan_bn_act_bwd_dt": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, c_int, c_int]),
     "agan_absmax": (c_int, [_P, c_size_t, _P, _P]),
     "agan_conv_wgrad_ws_bytes": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_wgrad": (c_int, [_P, _P, _P, POINTER(ConvGeom), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),

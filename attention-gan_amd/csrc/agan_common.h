@@ -121,6 +121,45 @@ __device__ __forceinline__ float amax_scale(float amax, float* inv) {
     return s;
 }
 
+// ---- typed access to activation tensors (include/agan.h: AGAN_DT_*): fp32, or 16-bit storage rounded to nearest even ------------
+typedef __bf16 agan_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 agan_f16x4 __attribute__((ext_vector_type(4)));
+typedef float agan_f32x4 __attribute__((ext_vector_type(4)));
+template <int DT> __device__ __forceinline__ float4 ld4(const void* p, size_t i) {          // elements i .. i+3 (i a multiple of 4)
+    if (DT == AGAN_DT_F32) return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
+    const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p) + i);
+    if (DT == AGAN_DT_BF16)
+        return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xFFFF0000u), __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
+    const agan_f32x4 v = __builtin_convertvector(__builtin_bit_cast(agan_f16x4, raw), agan_f32x4);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <int DT> __device__ __forceinline__ void st4(void* p, size_t i, float4 v) {
+    if (DT == AGAN_DT_F32) { *reinterpret_cast<float4*>(static_cast<float*>(p) + i) = v; return; }
+    const agan_f32x4 f = {v.x, v.y, v.z, v.w};
+    uint2 raw;
+    if (DT == AGAN_DT_BF16) raw = __builtin_bit_cast(uint2, __builtin_convertvector(f, agan_bf16x4));
+    else raw = __builtin_bit_cast(uint2, __builtin_convertvector(f, agan_f16x4));
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p) + i) = raw;
+}
+template <int DT> __device__ __forceinline__ float ld1(const void* p, size_t i) {
+    if (DT == AGAN_DT_F32) return static_cast<const float*>(p)[i];
+    const unsigned short h = static_cast<const unsigned short*>(p)[i];
+    if (DT == AGAN_DT_BF16) return __uint_as_float((unsigned)h << 16);
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int DT> __device__ __forceinline__ void st1(void* p, size_t i, float v) {
+    if (DT == AGAN_DT_F32) { static_cast<float*>(p)[i] = v; return; }
+    if (DT == AGAN_DT_BF16) static_cast<__bf16*>(p)[i] = (__bf16)v;
+    else static_cast<_Float16*>(p)[i] = (_Float16)v;
+}
+__host__ __device__ inline int dt_size(int dt) { return dt == AGAN_DT_F32 ? 4 : 2; }
+// rounds v to the storage type and back (what a consumer of the stored tensor will read)
+template <int DT> __device__ __forceinline__ float round_dt(float v) {
+    if (DT == AGAN_DT_F32) return v;
+    if (DT == AGAN_DT_BF16) return (float)(__bf16)v;
+    return (float)(_Float16)v;
+}
+
 // sum over a block of NT threads; result valid in every thread.  smem: NT/64 floats.
 template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* smem) {

@@ -29,7 +29,9 @@ __device__ __forceinline__ Chunk chunk_of(int n, int nchunk, int chunk) {
 // ---------------------------------------------------------------------------------------------------------
 // statistics
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int B, int C, int HW, int nchunk,
+// XDT: storage type of x (include/agan.h: AGAN_DT_*)
+template <int XDT>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __restrict__ x, int B, int C, int HW, int nchunk,
                                                                double* __restrict__ part) {
     __shared__ double red[2][4];
     const int c = blockIdx.x, chunk = blockIdx.y;
@@ -39,14 +41,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     if ((HW & 3) == 0) {
         for (int i = ch.beg + threadIdx.x * 4; i < ch.end; i += 1024) {
             const int b = i / HW, p = i - b * HW;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + p);
+            const float4 v = ld4<XDT>(x, ((size_t)b * C + c) * HW + p);
             s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         }
     } else {
         for (int i = ch.beg + threadIdx.x; i < ch.end; i += 256) {
             const int b = i / HW, p = i - b * HW;
-            const float v = x[((size_t)b * C + c) * HW + p];
+            const float v = ld1<XDT>(x, ((size_t)b * C + c) * HW + p);
             s += v;
             q += (double)v * v;
         }
@@ -130,11 +132,12 @@ __device__ __forceinline__ Affine affine_of(const float* mean, const float* invs
     return a;
 }
 
-template <int ACT, bool VEC>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+// XDT: storage type of x; ODT: of out and the residual
+template <int ACT, bool VEC, int XDT, int ODT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ res,
-                                                         float* __restrict__ out, int B, int C, int HW, float* __restrict__ amax) {
+                                                         const float* __restrict__ beta, const void* __restrict__ res,
+                                                         void* __restrict__ out, int B, int C, int HW, float* __restrict__ amax) {
     constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
     const size_t total = (size_t)B * Co * HW / V;
@@ -147,14 +150,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         const size_t xi = ((size_t)b * C + c) * HW + p;
         const Affine a = affine_of(mean, invstd, gamma, beta, c);
         float xv[4], yv[4];
-        if (VEC) *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + xi);
-        else xv[0] = x[xi];
+        if (VEC) *reinterpret_cast<float4*>(xv) = ld4<XDT>(x, xi);
+        else xv[0] = ld1<XDT>(x, xi);
         if (ACT == AGAN_ACT_GLU) {
             const Affine g = affine_of(mean, invstd, gamma, beta, c + Co);
             float gv[4];
             const size_t gi = xi + (size_t)Co * HW;
-            if (VEC) *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(x + gi);
-            else gv[0] = x[gi];
+            if (VEC) *reinterpret_cast<float4*>(gv) = ld4<XDT>(x, gi);
+            else gv[0] = ld1<XDT>(x, gi);
 #pragma unroll
             for (int k = 0; k < V; ++k) yv[k] = (xv[k] * a.s + a.t) * sigmoidf_(gv[k] * g.s + g.t);
         } else {
@@ -166,16 +169,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
             }
             if (res) {
                 float rv[4];
-                if (VEC) *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(res + i);
-                else rv[0] = res[i];
+                if (VEC) *reinterpret_cast<float4*>(rv) = ld4<ODT>(res, i);
+                else rv[0] = ld1<ODT>(res, i);
 #pragma unroll
                 for (int k = 0; k < V; ++k) yv[k] += rv[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) mx = fmaxf(mx, fabsf(yv[k]));
-        if (VEC) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<float4*>(yv);
-        else out[i] = yv[0];
+        if (VEC) st4<ODT>(out, i, *reinterpret_cast<float4*>(yv));
+        else st1<ODT>(out, i, yv[0]);
     }
     if (amax) amax_commit(mx, amax);
 }
@@ -201,8 +204,8 @@ __device__ __forceinline__ void dz_of(float xa, float xg, float d, const Affine&
     }
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+template <int ACT, int XDT, int ODT>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restrict__ x, const void* __restrict__ dout,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int B, int C, int HW, int nchunk, double* __restrict__ part) {
@@ -224,13 +227,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const size_t xi = ((size_t)b * C + c) * HW + p, di = ((size_t)b * Co + c) * HW + p;
         float xa[4], xg[4] = {0, 0, 0, 0}, d[4];
         if (vec) {
-            *reinterpret_cast<float4*>(xa) = *reinterpret_cast<const float4*>(x + xi);
-            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dout + di);
-            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = *reinterpret_cast<const float4*>(x + xi + (size_t)Co * HW);
+            *reinterpret_cast<float4*>(xa) = ld4<XDT>(x, xi);
+            *reinterpret_cast<float4*>(d) = ld4<ODT>(dout, di);
+            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = ld4<XDT>(x, xi + (size_t)Co * HW);
         } else {
-            xa[0] = x[xi];
-            d[0] = dout[di];
-            if (ACT == AGAN_ACT_GLU) xg[0] = x[xi + (size_t)Co * HW];
+            xa[0] = ld1<XDT>(x, xi);
+            d[0] = ld1<ODT>(dout, di);
+            if (ACT == AGAN_ACT_GLU) xg[0] = ld1<XDT>(x, xi + (size_t)Co * HW);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -275,11 +278,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
     coef[2 * c + 1] = (float)(q / n);
 }
 
-template <int ACT, bool VEC>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+template <int ACT, bool VEC, int XDT, int ODT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dout,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ coef, float* __restrict__ dx, int B, int C, int HW,
+                                                           const float* __restrict__ coef, void* __restrict__ dx, int B, int C, int HW,
                                                            float* __restrict__ amax) {
     constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
@@ -296,13 +299,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float ma = mean[c], ia = invstd[c], c0 = coef[2 * c], c1 = coef[2 * c + 1];
         float xa[4], xg[4] = {0, 0, 0, 0}, d[4], oa[4], og[4];
         if (VEC) {
-            *reinterpret_cast<float4*>(xa) = *reinterpret_cast<const float4*>(x + xi);
-            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dout + i);
-            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = *reinterpret_cast<const float4*>(x + xi + (size_t)Co * HW);
+            *reinterpret_cast<float4*>(xa) = ld4<XDT>(x, xi);
+            *reinterpret_cast<float4*>(d) = ld4<ODT>(dout, i);
+            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = ld4<XDT>(x, xi + (size_t)Co * HW);
         } else {
-            xa[0] = x[xi];
-            d[0] = dout[i];
-            if (ACT == AGAN_ACT_GLU) xg[0] = x[xi + (size_t)Co * HW];
+            xa[0] = ld1<XDT>(x, xi);
+            d[0] = ld1<ODT>(dout, i);
+            if (ACT == AGAN_ACT_GLU) xg[0] = ld1<XDT>(x, xi + (size_t)Co * HW);
         }
         float mg = 0, ig = 0, g0 = 0, g1 = 0;
         if (ACT == AGAN_ACT_GLU) { mg = mean[c + Co]; ig = invstd[c + Co]; g0 = coef[2 * (c + Co)]; g1 = coef[2 * (c + Co) + 1]; }
@@ -315,11 +318,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             if (ACT == AGAN_ACT_GLU) { og[k] = g.s * (dzg - g0 - (xg[k] - mg) * ig * g1); mx = fmaxf(mx, fabsf(og[k])); }
         }
         if (VEC) {
-            *reinterpret_cast<float4*>(dx + xi) = *reinterpret_cast<float4*>(oa);
-            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(dx + xi + (size_t)Co * HW) = *reinterpret_cast<float4*>(og);
+            st4<XDT>(dx, xi, *reinterpret_cast<float4*>(oa));
+            if (ACT == AGAN_ACT_GLU) st4<XDT>(dx, xi + (size_t)Co * HW, *reinterpret_cast<float4*>(og));
         } else {
-            dx[xi] = oa[0];
-            if (ACT == AGAN_ACT_GLU) dx[xi + (size_t)Co * HW] = og[0];
+            st1<XDT>(dx, xi, oa[0]);
+            if (ACT == AGAN_ACT_GLU) st1<XDT>(dx, xi + (size_t)Co * HW, og[0]);
         }
     }
     if (amax) amax_commit(mx, amax);
@@ -410,9 +413,9 @@ __device__ __forceinline__ void block_sum2_d(double& a, double& b, double (*red)
     b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ res, float* __restrict__ out, float* __restrict__ mean,
+template <int ACT, int XDT, int ODT>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const void* __restrict__ res, void* __restrict__ out, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
                                                            int64_t* __restrict__ nbt, int B, int C, int HW, float eps, float momentum,
                                                            float* __restrict__ amax) {
@@ -431,11 +434,11 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         if (i < n) {
             const int b = i / HW, p = i - b * HW;
             const size_t xi = ((size_t)b * C + c) * HW + p;
-            va[j] = x[xi];
+            va[j] = ld1<XDT>(x, xi);
             s += va[j];
             q += (double)va[j] * va[j];
             if (GLU) {
-                vg[j] = x[xi + (size_t)Co * HW];
+                vg[j] = ld1<XDT>(x, xi + (size_t)Co * HW);
                 sg += vg[j];
                 qg += (double)vg[j] * vg[j];
             }
@@ -485,18 +488,18 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
             float z = va[j] * sa + ta;
             if (GLU) z *= sigmoidf_(vg[j] * sgs + tg);
             else if (ACT == AGAN_ACT_LRELU) z = z >= 0.f ? z : z * kSlope;
-            if (!GLU && ACT == AGAN_ACT_NONE && res) z += res[oi];
-            out[oi] = z;
+            if (!GLU && ACT == AGAN_ACT_NONE && res) z += ld1<ODT>(res, oi);
+            st1<ODT>(out, oi, z);
             mx = fmaxf(mx, fabsf(z));
         }
     }
     if (amax) amax_commit(mx, amax);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ mean,
+template <int ACT, int XDT, int ODT>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dout, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           const float* __restrict__ beta, void* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int B, int C, int HW, int accumulate,
                                                            float* __restrict__ amax) {
     __shared__ double red[2][4];
@@ -517,10 +520,10 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         if (i < n) {
             const int b = i / HW, p = i - b * HW;
             const size_t xi = ((size_t)b * C + c) * HW + p;
-            xa[j] = x[xi];
-            const float d = dout[((size_t)b * Co + c) * HW + p];
+            xa[j] = ld1<XDT>(x, xi);
+            const float d = ld1<ODT>(dout, ((size_t)b * Co + c) * HW + p);
             float xgv = 0.f;
-            if (GLU) { xgv = x[xi + (size_t)Co * HW]; xg[j] = xgv; }
+            if (GLU) { xgv = ld1<XDT>(x, xi + (size_t)Co * HW); xg[j] = xgv; }
             float dza, dzg;
             dz_of<ACT>(xa[j], xgv, d, a, g, dza, dzg);
             za[j] = dza;
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
             const int b = i / HW, p = i - b * HW;
             const size_t xi = ((size_t)b * C + c) * HW + p;
             const float va = a.s * (za[j] - c0 - (xa[j] - ma) * ia * c1);
-            dx[xi] = va;
+            st1<XDT>(dx, xi, va);
             mx = fmaxf(mx, fabsf(va));
             if (GLU) {
                 const float vg2 = g.s * (zg[j] - g0 - (xg[j] - mg) * ig * g1);
-                dx[xi + (size_t)Co * HW] = vg2;
+                st1<XDT>(dx, xi + (size_t)Co * HW, vg2);
                 mx = fmaxf(mx, fabsf(vg2));
             }
         }
@@ -568,6 +571,21 @@ int ew_blocks(size_t work) { return (int)std::max<size_t>(1, std::min<size_t>(cd
 
 }  // namespace
 
+// storage-type combinations the BatchNorm kernels are built for: (x / dx, out / dout / residual)
+#define AGAN_BN_DT(XD, OD, CALL)                                                                                  \
+    do {                                                                                                          \
+        if ((XD) == AGAN_DT_F32 && (OD) == AGAN_DT_F32) { CALL(AGAN_DT_F32, AGAN_DT_F32); }                       \
+        else if ((XD) == AGAN_DT_BF16 && (OD) == AGAN_DT_BF16) { CALL(AGAN_DT_BF16, AGAN_DT_BF16); }              \
+        else if ((XD) == AGAN_DT_F32 && (OD) == AGAN_DT_BF16) { CALL(AGAN_DT_F32, AGAN_DT_BF16); }                \
+        else if ((XD) == AGAN_DT_F16 && (OD) == AGAN_DT_F16) { CALL(AGAN_DT_F16, AGAN_DT_F16); }                  \
+        else { CALL(AGAN_DT_F32, AGAN_DT_F16); }                                                                  \
+    } while (0)
+static bool bn_dt_ok(int xd, int od) {
+    return (xd == AGAN_DT_F32 && (od == AGAN_DT_F32 || od == AGAN_DT_BF16 || od == AGAN_DT_F16)) || (xd == od && (xd == AGAN_DT_BF16 || xd == AGAN_DT_F16));
+}
+static const void* off(const void* p, size_t elems, int dt) { return static_cast<const char*>(p) + elems * dt_size(dt); }
+static void* off(void* p, size_t elems, int dt) { return static_cast<char*>(p) + elems * dt_size(dt); }
+
 extern "C" {
 
 size_t agan_bn_stats_ws_bytes(int B, int C, int HW) {
@@ -575,14 +593,16 @@ size_t agan_bn_stats_ws_bytes(int B, int C, int HW) {
     return (size_t)C * stats_chunks(B, C, HW) * 2 * sizeof(double);
 }
 
-int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, float* invstd, float* running_mean,
-                  float* running_var, int64_t* nbt, float momentum, void* ws, size_t ws_bytes, void* stream) {
+int agan_bn_stats_dt(const void* x, int B, int C, int HW, float eps, float* mean, float* invstd, float* running_mean,
+                     float* running_var, int64_t* nbt, float momentum, void* ws, size_t ws_bytes, void* stream, int x_dtype) {
     AGAN_REQUIRE(x && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_stats: bad argument");
     AGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running_mean/var must come together");
+    AGAN_REQUIRE(x_dtype == AGAN_DT_F32 || x_dtype == AGAN_DT_BF16 || x_dtype == AGAN_DT_F16, "bn_stats: storage type %d", x_dtype);
     hipStream_t st = as_stream(stream);
     if (HW == 1) {
-        hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, B, C, eps, mean, invstd, running_mean,
-                           running_var, nbt, momentum);
+        AGAN_REQUIRE(x_dtype == AGAN_DT_F32, "bn_stats: [B, C] inputs (BatchNorm1d) are fp32 only");
+        hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, static_cast<const float*>(x), B, C, eps, mean, invstd,
+                           running_mean, running_var, nbt, momentum);
         return check_launch("bn_stats_rows");
     }
     const int nchunk = stats_chunks(B, C, HW);
@@ -591,28 +611,43 @@ int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, 
         return AGAN_EWORKSPACE;
     }
     double* part = static_cast<double*>(ws);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, nchunk), dim3(256), 0, st, x, B, C, HW, nchunk, part);
+    if (x_dtype == AGAN_DT_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<AGAN_DT_F32>, dim3(C, nchunk), dim3(256), 0, st, x, B, C, HW, nchunk, part);
+    else if (x_dtype == AGAN_DT_BF16) hipLaunchKernelGGL(bn_stats_partial_kernel<AGAN_DT_BF16>, dim3(C, nchunk), dim3(256), 0, st, x, B, C, HW, nchunk, part);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel<AGAN_DT_F16>, dim3(C, nchunk), dim3(256), 0, st, x, B, C, HW, nchunk, part);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, nchunk, B * HW, eps, mean, invstd,
                        running_mean, running_var, nbt, momentum);
     return check_launch("bn_stats");
 }
+int agan_bn_stats(const float* x, int B, int C, int HW, float eps, float* mean, float* invstd, float* running_mean,
+                  float* running_var, int64_t* nbt, float momentum, void* ws, size_t ws_bytes, void* stream) {
+    return agan_bn_stats_dt(x, B, C, HW, eps, mean, invstd, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream, AGAN_DT_F32);
+}
 
-int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                    const float* residual, float* out, int B, int C, int HW, int act, void* stream, float* out_amax) {
+int agan_bn_act_fwd_dt(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const void* residual, void* out, int B, int C, int HW, int act, void* stream, float* out_amax, int x_dtype,
+                       int out_dtype) {
     AGAN_REQUIRE(x && mean && invstd && gamma && beta && out && B > 0 && C > 0 && HW > 0, "bn_act_fwd: bad argument");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_fwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
     AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_act_fwd: residual only with ACT_NONE");
+    AGAN_REQUIRE(bn_dt_ok(x_dtype, out_dtype), "bn_act_fwd: storage types %d -> %d", x_dtype, out_dtype);
     hipStream_t st = as_stream(stream);
     const bool vec = (HW & 3) == 0;
     const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
     const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
-#define AGAN_L(A, V) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW, out_amax)
-    if (act == AGAN_ACT_GLU) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
-    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
-    else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
+#define AGAN_L(A, V, XD, OD) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V, XD, OD>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW, out_amax)
+#define AGAN_C(XD, OD)                                                                                               \
+    if (act == AGAN_ACT_GLU) { if (vec) AGAN_L(AGAN_ACT_GLU, true, XD, OD); else AGAN_L(AGAN_ACT_GLU, false, XD, OD); }   \
+    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true, XD, OD); else AGAN_L(AGAN_ACT_LRELU, false, XD, OD); } \
+    else { if (vec) AGAN_L(AGAN_ACT_NONE, true, XD, OD); else AGAN_L(AGAN_ACT_NONE, false, XD, OD); }
+    AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
+#undef AGAN_C
 #undef AGAN_L
     return check_launch("bn_act_fwd");
+}
+int agan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    const float* residual, float* out, int B, int C, int HW, int act, void* stream, float* out_amax) {
+    return agan_bn_act_fwd_dt(x, mean, invstd, gamma, beta, residual, out, B, C, HW, act, stream, out_amax, AGAN_DT_F32, AGAN_DT_F32);
 }
 
 static int bwd_chunks(int B, int C, int HW) { return stats_chunks(B, C, HW); }
@@ -621,13 +656,14 @@ size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW) {
     return (size_t)C * bwd_chunks(B, C, HW) * 4 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 64;
 }
 
-int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
-                    int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax) {
+int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, void* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
+                       int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax, int x_dtype, int out_dtype) {
     AGAN_REQUIRE(x && dout && mean && invstd && gamma && beta && dx && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_act_bwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
     AGAN_REQUIRE(groups >= 1 && B % groups == 0, "bn_act_bwd: batch %d does not split into %d groups", B, groups);
+    AGAN_REQUIRE(bn_dt_ok(x_dtype, out_dtype), "bn_act_bwd: storage types %d -> %d", x_dtype, out_dtype);
     const int Bg = B / groups;
     if (ws_bytes < agan_bn_act_bwd_ws_bytes(Bg, C, HW)) {
         set_error("bn_act_bwd: workspace too small");
@@ -638,14 +674,17 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
     const int Co = glu ? C / 2 : C;
     if (HW > 1 && (long long)Bg * HW <= kSmallN) {
         for (int gi = 0; gi < groups; ++gi) {      // (one launch per group: see agan_bn_train_fwd)
-            const float* xg = x + (size_t)gi * Bg * C * HW;
-            const float* dg = dout + (size_t)gi * Bg * Co * HW;
-            float* dxg = dx + (size_t)gi * Bg * C * HW;
+            const void* xg = off(x, (size_t)gi * Bg * C * HW, x_dtype);
+            const void* dg = off(dout, (size_t)gi * Bg * Co * HW, out_dtype);
+            void* dxg = off(dx, (size_t)gi * Bg * C * HW, x_dtype);
             const int acc = gi == 0 ? accumulate : 1;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc, dx_amax)
-            if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
-            else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
-            else AGAN_L(AGAN_ACT_NONE);
+#define AGAN_L(A, XD, OD) hipLaunchKernelGGL((bn_small_bwd_kernel<A, XD, OD>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc, dx_amax)
+#define AGAN_C(XD, OD)                                           \
+    if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU, XD, OD);       \
+    else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU, XD, OD); \
+    else AGAN_L(AGAN_ACT_NONE, XD, OD);
+            AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
+#undef AGAN_C
 #undef AGAN_L
         }
         return check_launch("bn_act_bwd/small");
@@ -657,23 +696,37 @@ int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const 
     const bool vec = (HW & 3) == 0;
     const int blocks = ew_blocks((size_t)Bg * Co * HW / (vec ? 4 : 1));
     for (int gi = 0; gi < groups; ++gi) {      // group 0 writes (or adds to) the gamma/beta gradients, the others add
-        const float* xg = x + (size_t)gi * Bg * C * HW;
-        const float* dg = dout + (size_t)gi * Bg * Co * HW;
+        const void* xg = off(x, (size_t)gi * Bg * C * HW, x_dtype);
+        const void* dg = off(dout, (size_t)gi * Bg * Co * HW, out_dtype);
         const float* mg = mean + (size_t)gi * C;
         const float* ig = invstd + (size_t)gi * C;
-        float* dxg = dx + (size_t)gi * Bg * C * HW;
+        void* dxg = off(dx, (size_t)gi * Bg * C * HW, x_dtype);
         const int acc = gi == 0 ? accumulate : 1;
-        if (glu) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_GLU>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
-        else if (act == AGAN_ACT_LRELU) hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_LRELU>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
-        else hipLaunchKernelGGL((bn_bwd_partial_kernel<AGAN_ACT_NONE>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part);
+#define AGAN_P(A, XD, OD) hipLaunchKernelGGL((bn_bwd_partial_kernel<A, XD, OD>), grid, dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, Bg, C, HW, nchunk, part)
+#define AGAN_C(XD, OD)                                           \
+    if (glu) AGAN_P(AGAN_ACT_GLU, XD, OD);                        \
+    else if (act == AGAN_ACT_LRELU) AGAN_P(AGAN_ACT_LRELU, XD, OD); \
+    else AGAN_P(AGAN_ACT_NONE, XD, OD);
+        AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
+#undef AGAN_C
+#undef AGAN_P
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, Bg * HW, glu, dgamma, dbeta, coef, acc);
-#define AGAN_L(A, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW, dx_amax)
-        if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true); else AGAN_L(AGAN_ACT_GLU, false); }
-        else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true); else AGAN_L(AGAN_ACT_LRELU, false); }
-        else { if (vec) AGAN_L(AGAN_ACT_NONE, true); else AGAN_L(AGAN_ACT_NONE, false); }
+#define AGAN_L(A, V, XD, OD) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V, XD, OD>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW, dx_amax)
+#define AGAN_C(XD, OD)                                                                                               \
+    if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true, XD, OD); else AGAN_L(AGAN_ACT_GLU, false, XD, OD); }               \
+    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true, XD, OD); else AGAN_L(AGAN_ACT_LRELU, false, XD, OD); } \
+    else { if (vec) AGAN_L(AGAN_ACT_NONE, true, XD, OD); else AGAN_L(AGAN_ACT_NONE, false, XD, OD); }
+        AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
+#undef AGAN_C
 #undef AGAN_L
     }
     return check_launch("bn_act_bwd");
+}
+int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
+                    int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax) {
+    return agan_bn_act_bwd_dt(x, dout, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, act, accumulate, groups, ws, ws_bytes,
+                              stream, dx_amax, AGAN_DT_F32, AGAN_DT_F32);
 }
 
 int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream) {
@@ -720,15 +773,17 @@ size_t agan_bn_train_fwd_ws_bytes(int B, int C, int HW) {
     return agan_bn_stats_ws_bytes(B, C, HW);
 }
 
-int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
-                      float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
-                      float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax) {
+int agan_bn_train_fwd_dt(const void* x, const float* gamma, const float* beta, const void* residual, void* out, float* mean,
+                         float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
+                         float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax, int x_dtype,
+                         int out_dtype) {
     AGAN_REQUIRE(x && gamma && beta && out && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_train_fwd: bad argument");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || act == AGAN_ACT_GLU || act == AGAN_ACT_LRELU, "bn_train_fwd: activation %d", act);
     AGAN_REQUIRE(act != AGAN_ACT_GLU || (C % 2 == 0), "channels dont divide 2!");
     AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_train_fwd: residual only with ACT_NONE");
     AGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running_mean/var must come together");
     AGAN_REQUIRE(groups >= 1 && B % groups == 0, "bn_train_fwd: batch %d does not split into %d groups", B, groups);
+    AGAN_REQUIRE(bn_dt_ok(x_dtype, out_dtype), "bn_train_fwd: storage types %d -> %d", x_dtype, out_dtype);
     const int Bg = B / groups;
     const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
     if (HW > 1 && (long long)Bg * HW <= kSmallN) {
@@ -736,29 +791,38 @@ int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
         // are latency-bound; two short ones overlap tail to head)
         hipStream_t st = as_stream(stream);
         for (int gi = 0; gi < groups; ++gi) {
-            const float* xg = x + (size_t)gi * Bg * C * HW;
-            const float* rg = residual ? residual + (size_t)gi * Bg * Co * HW : nullptr;
-            float* og = out + (size_t)gi * Bg * Co * HW;
+            const void* xg = off(x, (size_t)gi * Bg * C * HW, x_dtype);
+            const void* rg = residual ? off(residual, (size_t)gi * Bg * Co * HW, out_dtype) : nullptr;
+            void* og = off(out, (size_t)gi * Bg * Co * HW, out_dtype);
             float* mg = mean + (size_t)gi * C;
             float* ig = invstd + (size_t)gi * C;
-#define AGAN_L(A) hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum, out_amax)
-            if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU);
-            else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU);
-            else AGAN_L(AGAN_ACT_NONE);
+#define AGAN_L(A, XD, OD) hipLaunchKernelGGL((bn_small_fwd_kernel<A, XD, OD>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum, out_amax)
+#define AGAN_C(XD, OD)                                           \
+    if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU, XD, OD);       \
+    else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU, XD, OD); \
+    else AGAN_L(AGAN_ACT_NONE, XD, OD);
+            AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
+#undef AGAN_C
 #undef AGAN_L
         }
         return check_launch("bn_train_fwd/small");
     }
     for (int gi = 0; gi < groups; ++gi) {      // same stream: statistics, running-stat update and apply in group order
-        const float* xg = x + (size_t)gi * Bg * C * HW;
+        const void* xg = off(x, (size_t)gi * Bg * C * HW, x_dtype);
         float* mg = mean + (size_t)gi * C;
         float* ig = invstd + (size_t)gi * C;
-        if (int e = agan_bn_stats(xg, Bg, C, HW, eps, mg, ig, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream)) return e;
-        if (int e = agan_bn_act_fwd(xg, mg, ig, gamma, beta, residual ? residual + (size_t)gi * Bg * Co * HW : nullptr,
-                                    out + (size_t)gi * Bg * Co * HW, Bg, C, HW, act, stream, out_amax))
+        if (int e = agan_bn_stats_dt(xg, Bg, C, HW, eps, mg, ig, running_mean, running_var, nbt, momentum, ws, ws_bytes, stream, x_dtype)) return e;
+        if (int e = agan_bn_act_fwd_dt(xg, mg, ig, gamma, beta, residual ? off(residual, (size_t)gi * Bg * Co * HW, out_dtype) : nullptr,
+                                       off(out, (size_t)gi * Bg * Co * HW, out_dtype), Bg, C, HW, act, stream, out_amax, x_dtype, out_dtype))
             return e;
     }
     return AGAN_OK;
+}
+int agan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out, float* mean,
+                      float* invstd, float* running_mean, float* running_var, int64_t* nbt, int B, int C, int HW, float eps,
+                      float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax) {
+    return agan_bn_train_fwd_dt(x, gamma, beta, residual, out, mean, invstd, running_mean, running_var, nbt, B, C, HW, eps, momentum, act,
+                                groups, ws, ws_bytes, stream, out_amax, AGAN_DT_F32, AGAN_DT_F32);
 }
 
 }  // extern "C"

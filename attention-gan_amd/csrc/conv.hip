@@ -280,10 +280,12 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
 
 // out[i] = sum_s ws[s][i] (+ bias[channel]).  A workgroup covers 32 float4 elements x 8 split groups: each thread adds every
 // 8th slab (4 independent loads in flight), the 8 partial sums meet in LDS.  Deterministic (fixed summation order).
-__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
-                                                        const float* __restrict__ bias, int C, int HW,
-                                                        float* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE,
-                                                        const float* __restrict__ lrelu_mask = nullptr, float* __restrict__ amax = nullptr) {
+// ODT: storage type of out (and of lrelu_mask); accumulate needs AGAN_DT_F32.
+template <int ODT>
+__global__ __launch_bounds__(256) void sum_slabs_kernel_t(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
+                                                          const float* __restrict__ bias, int C, int HW,
+                                                          void* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE,
+                                                          const void* __restrict__ lrelu_mask = nullptr, float* __restrict__ amax = nullptr) {
     __shared__ float4 part[8][32];
     float mx = 0.f;
     const size_t n4 = n / 4;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
                 a.z += bias[((q + 2) / HW) % C]; a.w += bias[((q + 3) / HW) % C];
             }
             if (accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(out + i * 4);
+                const float4 o = ld4<ODT>(out, i * 4);
                 a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
             }
             if (act == AGAN_ACT_LRELU) {
@@ -329,11 +331,11 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
                 a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w;
             }
             if (lrelu_mask) {
-                const float4 m = *reinterpret_cast<const float4*>(lrelu_mask + i * 4);
+                const float4 m = ld4<ODT>(lrelu_mask, i * 4);
                 a.x = m.x > 0.f ? a.x : 0.2f * a.x; a.y = m.y > 0.f ? a.y : 0.2f * a.y;
                 a.z = m.z > 0.f ? a.z : 0.2f * a.z; a.w = m.w > 0.f ? a.w : 0.2f * a.w;
             }
-            *reinterpret_cast<float4*>(out + i * 4) = a;
+            st4<ODT>(out, i * 4, a);
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
         }
         __syncthreads();
@@ -344,14 +346,15 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
         float a = 0.f;
         for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * slab + q];
         if (bias) a += bias[(q / HW) % C];
-        if (accumulate) a += out[q];
+        if (accumulate) a += ld1<ODT>(out, q);
         if (act == AGAN_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
-        if (lrelu_mask) a = lrelu_mask[q] > 0.f ? a : 0.2f * a;
-        out[q] = a;
+        if (lrelu_mask) a = ld1<ODT>(lrelu_mask, q) > 0.f ? a : 0.2f * a;
+        st1<ODT>(out, q, a);
         mx = fmaxf(mx, fabsf(a));
     }
     if (amax) amax_commit(mx, amax);
 }
+#define sum_slabs_kernel sum_slabs_kernel_t<AGAN_DT_F32>      /* the fp32 form every fp32-storage call site uses */
 
 template <int BN, int WM, int WN>
 void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
@@ -863,7 +866,15 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     const Geom gg = make_geom(g);
     prec = agan_conv_effective_prec(g, prec);
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(gg)) return 0;
-    if (prec != AGAN_PREC_F32) return plan_patch_gather(gg, make_patch_plan(gg)).ws_bytes;
+    if (prec != AGAN_PREC_F32) {
+        size_t a = plan_patch_gather(gg, make_patch_plan(gg)).ws_bytes;
+        if (prec == AGAN_PREC_BF16 || prec == AGAN_PREC_F16)          // the row-block gather may split differently (either storage type)
+            for (int in16 = 0; in16 < 2; ++in16) {
+                const P16Plan p = plan_p16(gg, in16 != 0);
+                if (p.ok) a = std::max(a, p.ws_bytes);
+            }
+        return a;
+    }
     return plan_gather(gg, prec).ws_bytes;
 }
 
@@ -882,15 +893,34 @@ int agan_conv_ktable(const agan_conv_geom* gg, int32_t* table, void* stream) {
     return check_launch("conv_ktable");
 }
 
-int agan_conv_gather(const float* in, const void* wkv, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
-                     int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream, const float* in_scale,
-                     float* out_amax) {
+// does the row-block gather (conv_p16.hip) take this call?  (one-plane 16-bit modes; AGAN_P16_OFF=1 keeps fp32-storage calls on
+// the patch-resident kernel for A/B measurements)
+static bool p16_takes(const Geom& g, int prec, int in_dtype, int out_dtype, P16Plan* plan) {
+    if (prec != AGAN_PREC_BF16 && prec != AGAN_PREC_F16) return false;
+    const int want = prec == AGAN_PREC_BF16 ? AGAN_DT_BF16 : AGAN_DT_F16;
+    if ((in_dtype != AGAN_DT_F32 && in_dtype != want) || (out_dtype != AGAN_DT_F32 && out_dtype != want)) return false;
+    static const bool off = getenv("AGAN_P16_OFF") != nullptr;
+    if (off && in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32) return false;
+    const P16Plan p = plan_p16(g, in_dtype != AGAN_DT_F32);
+    if (plan) *plan = p;
+    return p.ok != 0;
+}
+
+int agan_conv_gather_dt_supported(const agan_conv_geom* gg, int prec, int in_dtype, int out_dtype) {
+    if (check_geom(gg)) return 0;
+    if (in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32) return 1;
+    return p16_takes(make_geom(gg), prec, in_dtype, out_dtype, nullptr) ? 1 : 0;
+}
+
+int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, void* out_v, const agan_conv_geom* gg, const int32_t* ktable,
+                        int prec, int act, const void* lrelu_mask_v, void* ws, size_t ws_bytes, void* stream, const float* in_scale,
+                        float* out_amax, int in_dtype, int out_dtype) {
     const float* wk = static_cast<const float*>(wkv);
     if (int e = check_geom(gg)) return e;
-    AGAN_REQUIRE(in && wk && out && ktable, "conv_gather: null pointer");
+    AGAN_REQUIRE(in_v && wk && out_v && ktable, "conv_gather: null pointer");
     AGAN_REQUIRE(act == AGAN_ACT_NONE || (act == AGAN_ACT_LRELU && gg->Cout > 4),
                  "conv_gather: fused activation %d not available for this call (MFMA paths, LeakyReLU only)", act);
-    AGAN_REQUIRE(!lrelu_mask || (gg->Cout > 4 && act == AGAN_ACT_NONE),
+    AGAN_REQUIRE(!lrelu_mask_v || (gg->Cout > 4 && act == AGAN_ACT_NONE),
                  "conv_gather: the LeakyReLU-derivative mask needs an MFMA path and no other activation");
     const int2* ktab = reinterpret_cast<const int2*>(ktable);
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_gather: unknown precision mode %d", prec);
@@ -898,6 +928,38 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
                  "conv_gather: precision mode %d does not take this geometry (agan_conv_effective_prec says which one does)", prec);
     const Geom g = make_geom(gg);
     hipStream_t st = as_stream(stream);
+    {
+        P16Plan p16;
+        if (p16_takes(g, prec, in_dtype, out_dtype, &p16)) {
+            if (p16.ws_bytes > ws_bytes || (p16.ws_bytes && !ws)) {
+                set_error("conv_gather: workspace %zu < %zu", ws_bytes, p16.ws_bytes);
+                return AGAN_EWORKSPACE;
+            }
+            void* dst = p16.ksplit > 1 ? ws : out_v;
+            timer_begin(st);
+            launch_p16_gather(in_v, wkv, bias, dst, g, p16, prec, act, lrelu_mask_v, st, in_dtype != AGAN_DT_F32, out_dtype != AGAN_DT_F32);
+            timer_end(st);
+            if (int e = check_launch("conv_gather/p16")) return e;
+            if (p16.ksplit > 1) {
+                const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
+                const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
+#define AGAN_SUM_DT(DT) hipLaunchKernelGGL(sum_slabs_kernel_t<DT>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p16.ksplit, n, \
+                                           p16.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v, (float*)nullptr)
+                if (out_dtype == AGAN_DT_F32) AGAN_SUM_DT(AGAN_DT_F32);
+                else if (out_dtype == AGAN_DT_BF16) AGAN_SUM_DT(AGAN_DT_BF16);
+                else AGAN_SUM_DT(AGAN_DT_F16);
+#undef AGAN_SUM_DT
+                return check_launch("conv_gather/p16/sum_slabs");
+            }
+            return AGAN_OK;
+        }
+    }
+    AGAN_REQUIRE(in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32,
+                 "conv_gather: 16-bit activation storage (%d -> %d) is not available for this geometry / precision %d "
+                 "(agan_conv_gather_dt_supported)", in_dtype, out_dtype, prec);
+    const float* in = static_cast<const float*>(in_v);
+    float* out = static_cast<float*>(out_v);
+    const float* lrelu_mask = static_cast<const float*>(lrelu_mask_v);
     if (prec != AGAN_PREC_F32) {
         const PatchPlan pp = make_patch_plan(g);
         const PatchGather p = plan_patch_gather(g, pp);
@@ -948,6 +1010,13 @@ int agan_conv_gather(const float* in, const void* wkv, const float* bias, float*
     return AGAN_OK;
 }
 
+int agan_conv_gather(const float* in, const void* wkv, const float* bias, float* out, const agan_conv_geom* gg, const int32_t* ktable,
+                     int prec, int act, const float* lrelu_mask, void* ws, size_t ws_bytes, void* stream, const float* in_scale,
+                     float* out_amax) {
+    return agan_conv_gather_dt(in, wkv, bias, out, gg, ktable, prec, act, lrelu_mask, ws, ws_bytes, stream, in_scale, out_amax,
+                               AGAN_DT_F32, AGAN_DT_F32);
+}
+
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (check_geom(g)) return 0;
     const Geom gg = make_geom(g);
@@ -961,9 +1030,32 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     return a;
 }
 
+// 1 if agan_conv_wgrad_dt takes x / dy in these storage types for forward geometry g (both fp32: always; 16-bit: the one-plane patch
+// weight gradient in the matching mode)
+int agan_conv_wgrad_dt_supported(const agan_conv_geom* gg, int pack_mode, int prec, int x_dtype, int dy_dtype) {
+    if (check_geom(gg)) return 0;
+    if (x_dtype == AGAN_DT_F32 && dy_dtype == AGAN_DT_F32) return 1;
+    if (prec != AGAN_PREC_BF16 && prec != AGAN_PREC_F16) return 0;
+    const int want = prec == AGAN_PREC_BF16 ? AGAN_DT_BF16 : AGAN_DT_F16;
+    if ((x_dtype != AGAN_DT_F32 && x_dtype != want) || (dy_dtype != AGAN_DT_F32 && dy_dtype != want)) return 0;
+    return agan_conv_wgrad_effective_prec(gg, pack_mode, prec) == prec ? 1 : 0;
+}
+
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
                     int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream, const float* x_scale,
                     const float* dy_scale) {
+    return agan_conv_wgrad_dt(x, dy, dw, gg, ktable, pack_mode, kh, kw, prec, accumulate, ws, ws_bytes, stream, x_scale, dy_scale,
+                              AGAN_DT_F32, AGAN_DT_F32);
+}
+
+int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_conv_geom* gg, const int32_t* ktable, int pack_mode,
+                       int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream, const float* x_scale,
+                       const float* dy_scale, int x_dtype, int dy_dtype) {
+    AGAN_REQUIRE(agan_conv_wgrad_dt_supported(gg, pack_mode, prec, x_dtype, dy_dtype),
+                 "conv_wgrad: 16-bit activation storage (%d, %d) is not available for this geometry / precision %d", x_dtype, dy_dtype, prec);
+    const float* x = static_cast<const float*>(x_v);
+    const float* dy = static_cast<const float*>(dy_v);
+
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
@@ -987,7 +1079,7 @@ int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_
         float* reduced = p.psplit > 1 ? wsf + p.slab * p.psplit : wsf;
         timer_begin(st);
         AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
-        launch_patch_wgrad(x, dy, wsf, g, pp, p, prec, st, x_scale, dy_scale);
+        launch_patch_wgrad(x_v, dy_v, wsf, g, pp, p, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
         timer_end(st);
         if (int e = check_launch("conv_wgrad/patch")) return e;
         if (p.psplit > 1) {

@@ -280,10 +280,27 @@ struct PatchWgrad {
     int bj, jtiles, ncls, psplit, tiles_per_split, Kp;
     size_t slab, ws_bytes;
 };
+// ---- row-block staging gather for the one-plane 16-bit modes, fp32 or 16-bit activation storage (conv_p16.hip) --------------------
+struct P16Plan {
+    int ok;                             // 0: the kernel does not take this geometry
+    int gk;                             // 0: 3x3 s1, 1: 2x2 s1 (parity classes), 2: 4x4 s2
+    int twl, thl, TB;                   // tile = TB images x 2^thl rows x 2^twl columns of the output lattice (128 points)
+    int tiles_x, tiles_y, tiles_b, mtiles;
+    int PH, LW, NXB, PXB, CHS;          // patch rows per image, LDS row width (positions), 16-byte blocks per row, pixels per block, channels per stage
+    int nitems, NI;                     // staging items per stage / per thread
+    int nstages, wsteps;                // stages (CHS-channel chunks); k-steps of the packed weights per class
+    int bn, ntiles, ncls, ksplit, stages_per_split;
+    int buf_bytes;                      // one LDS patch buffer (the kernel holds two)
+    size_t slab, ws_bytes;
+    FastDiv dNXB, dPH, dTB;
+};
+P16Plan plan_p16(const Geom& g, bool in16);
+void launch_p16_gather(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int prec, int act,
+                       const void* lrelu_mask, hipStream_t st, bool in16, bool out16);
 int prec_planes(int prec);
 PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec);
-void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
-                        hipStream_t st, const float* x_scale = nullptr, const float* dy_scale = nullptr);
+void launch_patch_wgrad(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
+                        hipStream_t st, const float* x_scale = nullptr, const float* dy_scale = nullptr, bool x16 = false, bool y16 = false);
 constexpr float kF16WeightScale = 2048.f;      // AGAN_PREC_F16X3 packs weights times 2^11 (|w| < 32 keeps fp16 finite)
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,
                                int accumulate, hipStream_t st);

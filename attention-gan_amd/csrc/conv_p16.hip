@@ -1,0 +1,403 @@
+// Row-block staging gather for the one-plane 16-bit matrix-core modes (AGAN_PREC_BF16 / AGAN_PREC_F16), with optional 16-BIT
+// ACTIVATION STORAGE in HBM (round 3; include/agan.h: AGAN_DT_*).
+//
+// What bounded the patch-resident kernel of conv_patch.hip in these modes (11-18 % MFMA-busy in round 2) was not the matrix pipe
+// and not HBM: every staged value was ONE 4-byte-per-lane global load -- 40 vector-memory instructions per thread and stage, six
+// per 128-cycle k-step and wave, more than the texture-address path of a CU issues -- and, loads returning in order, the first
+// weight fragment fetched after that burst waited for all of it.  Here a lane loads 16 BYTES of one NCHW row -- 4 fp32 or 8
+// 16-bit pixels of one channel -- for 8 channels (8 loads per thread and stage instead of 40), transposes the 8 x PXB block in
+// registers (v_perm_b32 / v_cvt_pk) and writes PXB [position][8 channels] items with ds_write_b128.  The LDS image is the FULL
+// input patch of the tile: stride-2 convolutions no longer run as four phase stages with their own gathers -- the patch rows are
+// kept de-interleaved ([even x | odd x]), so a tap of a stride-2 conv is still a unit-stride ds_read_b128 across the 32 pixels
+// of a tile row.  With 16-bit storage nothing is converted at all on the way in, half the bytes move, and the epilogue rounds
+// once to the storage type.  The weight fragments (packed exactly as for conv_patch.hip: [class][k-step][cout][16]) come
+// straight from L2 through a register ring 8-9 k-steps deep.
+//
+// Geometry kinds (GK):   0  3x3 stride 1          32 channels per stage, 18 k-steps
+//                        1  2x2 stride 1          64 channels per stage, 16 k-steps  (parity classes of conv4x4-s2 dgrad / upsample conv)
+//                        2  4x4 stride 2          16 channels per stage, 16 k-steps  (all four input phases in one stage)
+// Accumulators are D[cout][pixel] as in the other conv kernels; BN x 128-pixel workgroup tiles, 4 waves.
+#include "conv_common.h"
+
+#include <cstring>
+
+using namespace agan;
+using namespace agan::conv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ u32x4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <int ET>
+__device__ __forceinline__ unsigned pack2(float a, float b) {          // two fp32 -> two 16-bit values, round to nearest even
+    f32x2 v = {a, b};
+    if (ET == 0) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+template <int ET>
+__device__ __forceinline__ float up16(unsigned short h) {              // 16-bit storage value -> fp32
+    if (ET == 0) return __uint_as_float((unsigned)h << 16);
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int ET>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if (ET == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int GK> struct GKTraits;
+template <> struct GKTraits<0> { static constexpr int R = 3, S = 3, IS = 1, CHS = 32; };
+template <> struct GKTraits<1> { static constexpr int R = 2, S = 2, IS = 1, CHS = 64; };
+template <> struct GKTraits<2> { static constexpr int R = 4, S = 4, IS = 2, CHS = 16; };
+
+// ET: 0 bf16 / 1 f16 (MFMA operand type = 16-bit storage type).  IN16 / OUT16: the gathered / produced tensor is stored in that
+// 16-bit type (else fp32).  NI: staging items per thread and stage.
+template <int ET, int GK, int BN, bool IN16, bool OUT16, int NI>
+__global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict__ in, const unsigned short* __restrict__ wk,
+                                                          const float* __restrict__ bias, void* __restrict__ out, const Geom g,
+                                                          const P16Plan pp, const int act, const void* __restrict__ lrelu_mask) {
+    using T = GKTraits<GK>;
+    constexpr int R = T::R, S = T::S, IS = T::IS, CHS = T::CHS;
+    constexpr int NT = R * S;
+    constexpr int HS = CHS / 16;                     // 16-channel k-steps per tap (GK 2: one)
+    constexpr int SPS = GK == 2 ? NT : NT * HS;      // k-steps per stage: 18 / 16 / 16
+    constexpr int PB = CHS * 2 + 16;                 // LDS bytes per position: an odd multiple of 16 B (conflict-free b128 rows)
+    constexpr int PXB = IN16 ? 8 : 4;                // pixels per 16-byte load
+    constexpr int ESZ = IN16 ? 2 : 4;
+    constexpr int WD = SPS == 18 ? 9 : 8;            // weight ring depth (divides SPS)
+    constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
+    constexpr int NWR = NI * PXB;                    // LDS item writes per thread and stage
+    constexpr int U0 = SPS / 2;                      // first k-step that carries item writes: the loads get SPS/2 k-steps to land
+    constexpr int WPS = (NWR + (SPS - U0) - 1) / (SPS - U0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int buf_bytes = pp.buf_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ksplit = pp.ksplit;
+    int mt, nt, cls, split;
+    {
+        const int ncls = pp.ncls, mtiles = pp.mtiles, ntiles = pp.ntiles;
+        int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * ncls * ksplit);
+        nt = F % ntiles; F /= ntiles;
+        cls = F % ncls;  F /= ncls;
+        mt = F % mtiles; split = F / mtiles;
+    }
+    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int n0 = nt * BN;
+    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+    const int twl = pp.twl, thl = pp.thl;
+    const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+    const int ihw = g.IH * g.IW;
+    const int stage_beg = split * pp.stages_per_split, stage_end = min(pp.nstages, stage_beg + pp.stages_per_split);
+
+    // patch origin in the gathered tensor (row / column of LDS row 0 / of the first needed column), and the aligned column the
+    // 16-byte blocks start at
+    const int dmin = (IS == 1 && g.DY < 0) ? -(R - 1) : 0;
+    const int y0 = IS * ty0 + dmin + (py ? g.OY1 : g.OY0), x0 = IS * tx0 + dmin + (px ? g.OY1 : g.OY0);
+    const int gx0 = x0 & ~(PXB - 1);
+    const int dx0 = x0 - gx0;
+    const int LW = pp.LW, LWH = LW >> 1;
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * ESZ);
+    const size_t wbytes_cls = (size_t)pp.wsteps * g.Nld * 32;
+    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)cls * wbytes_cls, wbytes_cls);
+
+    // ---- staging items: (channel octet o, image pb, patch row j, 16-byte block xb), xb fastest (lanes walk along a row) ----
+    unsigned it_voff[NI], it_lds[NI];
+    int it_oct[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int t1 = pp.dNXB.div(e), xb = e - t1 * pp.NXB;
+        const int t2 = pp.dPH.div(t1), j = t1 - t2 * pp.PH;
+        const int o = pp.dTB.div(t2), pb = t2 - o * pp.TB;
+        const int b = tb0 + pb, iy = y0 + j, gx = gx0 + xb * PXB;
+        const bool ok = (e < pp.nitems) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)gx < (unsigned)g.IW);
+        it_oct[i] = (e < pp.nitems) ? o : CHS;          // (>= CHS/8: no channel of any stage)
+        it_voff[i] = ok ? (unsigned)(((b * g.Cin + o * 8) * g.IH + iy) * g.IW + gx) * (unsigned)ESZ : kOOB;
+        const int row = pb * pp.PH + j;
+        it_lds[i] = (unsigned)((row * LW + (IS == 1 ? xb * PXB : xb * (PXB / 2))) * PB + o * 16);
+    }
+    const unsigned oddoff = (unsigned)(LWH * PB);        // IS == 2: odd columns live in the second half of an LDS row
+    u32x4 blk[NI][8];
+    auto load_items = [&](int chunk) {
+        const int c0 = chunk * CHS;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const unsigned voff = (c0 + it_oct[i] * 8 < g.Cin && it_oct[i] < CHS / 8) ? it_voff[i] : kOOB;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) blk[i][c] = ld16(rin, voff, (unsigned)((c0 + c) * ihw) * (unsigned)ESZ);
+        }
+    };
+    // item write w of a stage = pixel q of item i: transpose on the fly, one ds_write_b128
+    auto store_piece = [&](int w, unsigned char* dstbuf) {
+        const int i = w / PXB, q = w % PXB;
+        if (i >= NI) return;
+        u32x4 v;
+        if (IN16) {
+            const int d = q >> 1;
+            const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_perm(blk[i][2 * k + 1][d], blk[i][2 * k][d], sel);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = pack2<ET>(__uint_as_float(blk[i][2 * k][q]), __uint_as_float(blk[i][2 * k + 1][q]));
+        }
+        const unsigned a = IS == 1 ? it_lds[i] + (unsigned)(q * PB) : it_lds[i] + ((q & 1) ? oddoff : 0u) + (unsigned)((q >> 1) * PB);
+        if (it_oct[i] < CHS / 8) *reinterpret_cast<u32x4*>(dstbuf + a) = v;
+    };
+
+    // ---- MFMA operand addressing ----
+    unsigned lbase[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        lbase[t] = (unsigned)(((tb * pp.PH + IS * ty) * LW + tx + (IS == 1 ? dx0 : 0)) * PB + lh * 16);
+    }
+    unsigned tapoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = t / S, s = t - r * S;
+        if (IS == 1) {
+            const int ro = r * g.DY - dmin, so = s * g.DY - dmin;
+            tapoff[t] = (unsigned)((ro * LW + so) * PB);
+        } else {
+            const int xs = s + dx0;
+            tapoff[t] = (unsigned)((r * LW + (xs & 1) * LWH + (xs >> 1)) * PB);
+        }
+    }
+    // k-step u of a stage -> (tap, byte offset of its 16 channels inside a position, k-step of the packed weights)
+    auto tap_of = [&](int u) { return GK == 2 ? u : (GK == 0 ? u / 2 : (u & 7) / 2); };
+    auto choff_of = [&](int u) { return GK == 2 ? 0 : (GK == 0 ? (u & 1) * 32 : (u >> 3) * 64 + (u & 1) * 32); };
+    // packed weights (conv_patch.hip): q = ((chunk32 * NPH + phase) * NT' + tap') * 2 + half
+    auto wq_of = [&](int stage, int u) {
+        if (GK == 0) return stage * 18 + u;                                   // chunk32 = stage; u = tap * 2 + half
+        if (GK == 1) return stage * 16 + u;                                   // two chunk32 per stage; u = c32 * 8 + tap * 2 + half
+        const int r = u >> 2, s = u & 3;                                      // GK 2: stage = (chunk32, half); u = tap (r, s)
+        const int ph = (r & 1) * 2 + (s & 1), tp = (r >> 1) * 2 + (s >> 1);
+        return (((stage >> 1) * 4 + ph) * 4 + tp) * 2 + (stage & 1);
+    };
+    const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    const unsigned wstep = (unsigned)(g.Nld * 32);
+    u32x4 wf[WD];
+    auto load_w = [&](int slot, int q) { wf[slot] = ld16(rwk, wlane, (unsigned)min(q, pp.wsteps - 1) * wstep); };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (stage_beg < stage_end) {
+#pragma unroll
+        for (int d = 0; d < WD; ++d) load_w(d, wq_of(stage_beg, d));
+        load_items(stage_beg);
+#pragma unroll
+        for (int w = 0; w < NWR; ++w) store_piece(w, lds + (stage_beg & 1) * buf_bytes);
+        lds_barrier();
+        for (int stage = stage_beg; stage < stage_end; ++stage) {
+            const bool more = stage + 1 < stage_end;
+            const unsigned char* cur = lds + (stage & 1) * buf_bytes;
+            unsigned char* nxt = lds + ((stage + 1) & 1) * buf_bytes;
+            if (more) load_items(stage + 1);
+            u32x4 af[2][TM];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) af[0][m] = *reinterpret_cast<const u32x4*>(cur + lbase[m] + tapoff[tap_of(0)] + choff_of(0));
+#pragma unroll
+            for (int u = 0; u < SPS; ++u) {
+                const u32x4 w = wf[u % WD];
+                {   // weights WD k-steps ahead (possibly in the next stage; past the last stage: a harmless repeat)
+                    const int u2 = u + WD;
+                    if (u2 < SPS) load_w(u % WD, wq_of(stage, u2));
+                    else load_w(u % WD, wq_of(more ? stage + 1 : stage, u2 - SPS));
+                }
+                if (u + 1 < SPS) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        af[(u + 1) & 1][m] = *reinterpret_cast<const u32x4*>(cur + lbase[m] + tapoff[tap_of(u + 1)] + choff_of(u + 1));
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[m] = mfma16<ET>(w, af[u & 1][m], acc[m]);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);      // next step's LDS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);      // ... then this step's MFMAs
+                if (u >= U0 && more) {
+#pragma unroll
+                    for (int k = 0; k < WPS; ++k)
+                        if ((u - U0) * WPS + k < NWR) store_piece((u - U0) * WPS + k, nxt);
+                }
+            }
+            lds_barrier();
+        }
+    }
+
+    // ---- epilogue: D[cout][pixel]; a register holds 32 consecutive pixels of one output channel ----
+    const size_t ohw = (size_t)g.OH * g.OW;
+    const bool split_out = ksplit > 1;                  // partial sums go to fp32 slabs; the slab sum applies bias / activation / rounding
+    const bool add_bias = (bias != nullptr) && !split_out;
+    const bool lrelu = (act == AGAN_ACT_LRELU) && !split_out;
+    const bool masked = (lrelu_mask != nullptr) && !split_out;
+    const size_t nelem = (size_t)g.B * g.Cout * ohw;
+    const __amdgpu_buffer_rsrc_t rslab = make_rsrc(split_out ? static_cast<float*>(out) + (size_t)split * pp.slab : static_cast<float*>(out),
+                                                   nelem * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, nelem * (OUT16 ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : out, nelem * (OUT16 ? 2 : 4));
+    const int nw = n0 + wn * 32;
+    const bool nfull = nw + 32 <= g.Cout;
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : static_cast<const float*>(out), (size_t)g.Cout * sizeof(float));
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+        const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+        const unsigned pix = (unsigned)(b * g.Cout + nw + 4 * lh) * (unsigned)ohw + (unsigned)((yq * g.OS + py) * g.OW + (xq * g.OS + px));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nr = (r & 3) + 8 * (r >> 2);
+            float v = acc[t][r];
+            const bool ok = pvalid & (nfull || (nw + nr + 4 * lh < g.Cout));
+            if (split_out) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rslab, ok ? pix * 4u : kOOB, (unsigned)nr * (unsigned)ohw * 4u, 0);
+                continue;
+            }
+            if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
+            if (lrelu) v = v > 0.f ? v : 0.2f * v;
+            if (OUT16) {
+                const unsigned vo = ok ? pix * 2u : kOOB, so = (unsigned)nr * (unsigned)ohw * 2u;
+                if (masked) v = up16<ET>((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rmask, vo, so, 0)) > 0.f ? v : 0.2f * v;
+                __builtin_amdgcn_raw_buffer_store_b16((short)(pack2<ET>(v, 0.f) & 0xFFFFu), rout, vo, so, 0);
+            } else {
+                const unsigned vo = ok ? pix * 4u : kOOB, so = (unsigned)nr * (unsigned)ohw * 4u;
+                if (masked) v = buf_load_s(rmask, vo, so) > 0.f ? v : 0.2f * v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, so, 0);
+            }
+        }
+    }
+}
+
+template <int ET, int GK, int BN, bool IN16, bool OUT16>
+void launch_ni(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
+               hipStream_t st) {
+    dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
+    const unsigned short* w = static_cast<const unsigned short*>(wk);
+    const size_t smem = (size_t)2 * p.buf_bytes;
+#define AGAN_P16_LAUNCH(NI_)                                                                                                             \
+    do {                                                                                                                                 \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+        (void)attr_;                                                                                                                     \
+        hipLaunchKernelGGL((conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask); \
+    } while (0)
+    if (p.NI == 1) AGAN_P16_LAUNCH(1);
+    else AGAN_P16_LAUNCH(2);
+#undef AGAN_P16_LAUNCH
+}
+template <int ET, int GK, int BN>
+void launch_dt(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
+               hipStream_t st, bool in16, bool out16) {
+    if (in16 && out16) launch_ni<ET, GK, BN, true, true>(in, wk, bias, dst, g, p, act, mask, st);
+    else if (in16) launch_ni<ET, GK, BN, true, false>(in, wk, bias, dst, g, p, act, mask, st);
+    else if (out16) launch_ni<ET, GK, BN, false, true>(in, wk, bias, dst, g, p, act, mask, st);
+    else launch_ni<ET, GK, BN, false, false>(in, wk, bias, dst, g, p, act, mask, st);
+}
+template <int ET, int GK>
+void launch_bn(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
+               hipStream_t st, bool in16, bool out16) {
+    if (p.bn == 128) launch_dt<ET, GK, 128>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+    else if (p.bn == 64) launch_dt<ET, GK, 64>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+    else launch_dt<ET, GK, 32>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+}
+template <int ET>
+void launch_gk(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
+               hipStream_t st, bool in16, bool out16) {
+    if (p.gk == 0) launch_bn<ET, 0>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+    else if (p.gk == 1) launch_bn<ET, 1>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+    else launch_bn<ET, 2>(in, wk, bias, dst, g, p, act, mask, st, in16, out16);
+}
+
+int pow2ceil_log_(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+namespace agan {
+namespace conv {
+
+// Plan of the row-block gather for geometry g with the gathered tensor stored as fp32 (in16 = false) or in 16 bits.  p.ok == 0:
+// this kernel does not take the call (the caller falls back to conv_patch.hip's kernel on fp32 tensors).
+P16Plan plan_p16(const Geom& g, bool in16) {
+    P16Plan p;
+    memset(&p, 0, sizeof(p));
+    if (g.Cout <= 4 || g.Cin <= 4 || (g.Cin & 7)) return p;
+    int R, IS, CHS;
+    if (g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1) { p.gk = 0; R = 3; IS = 1; CHS = 32; }
+    else if (g.SY == 1 && g.R == 2 && g.S == 2 && (g.DY == 1 || g.DY == -1)) { p.gk = 1; R = 2; IS = 1; CHS = 64; }
+    else if (g.SY == 2 && g.R == 4 && g.S == 4 && g.DY == 1) { p.gk = 2; R = 4; IS = 2; CHS = 16; }
+    else return p;
+    p.PXB = in16 ? 8 : 4;
+    if (g.IW % p.PXB) return p;                       // rows of the gathered tensor must be whole 16-byte blocks
+    p.twl = std::min(5, pow2ceil_log_(g.OWs));
+    p.thl = std::min(7 - p.twl, pow2ceil_log_(g.OHs));
+    const int TW = 1 << p.twl, TH = 1 << p.thl;
+    p.TB = 128 >> (p.twl + p.thl);
+    p.tiles_x = cdiv(g.OWs, TW);
+    p.tiles_y = cdiv(g.OHs, TH);
+    p.tiles_b = cdiv(g.B, p.TB);
+    p.mtiles = p.tiles_x * p.tiles_y * p.tiles_b;
+    p.PH = IS * (TH - 1) + R;
+    const int PW = IS * (TW - 1) + R;
+    p.NXB = cdiv(p.PXB - 1 + PW, p.PXB);              // blocks that cover the patch columns whatever the alignment of its origin
+    p.LW = p.NXB * p.PXB;
+    p.CHS = CHS;
+    p.nitems = (CHS / 8) * p.TB * p.PH * p.NXB;
+    p.NI = cdiv(p.nitems, 256);
+    if (p.NI > 2) return p;
+    p.buf_bytes = p.TB * p.PH * p.LW * (CHS * 2 + 16);
+    // (two workgroups per CU up to 78 KB; the 8x8 / 16x16 layers, whose tiles span several images, take up to 150 KB and run one)
+    if (2 * p.buf_bytes > 150 * 1024) return p;
+    p.nstages = cdiv(g.Cin, CHS);
+    // k-steps of the packed weights (conv_patch.hip layout: 32-channel chunks x phases x taps x 2)
+    p.wsteps = cdiv(g.Cin, 32) * (IS == 2 ? 4 : 1) * (IS == 2 ? 4 : R * R) * 2;
+    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
+    p.ntiles = cdiv(g.Cout, p.bn);
+    p.ncls = g.OS * g.OS;
+    const int tiles = p.mtiles * p.ntiles * p.ncls;
+    int ks = 1;
+    if (tiles < 512) ks = std::max(1, std::min({512 / tiles, p.nstages / 4, 32}));
+    p.stages_per_split = cdiv(p.nstages, ks);
+    p.ksplit = cdiv(p.nstages, p.stages_per_split);
+    p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
+    p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
+    p.dNXB = make_fastdiv((unsigned)p.NXB);
+    p.dPH = make_fastdiv((unsigned)p.PH);
+    p.dTB = make_fastdiv((unsigned)p.TB);
+    p.ok = 1;
+    return p;
+}
+
+void launch_p16_gather(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int prec, int act,
+                       const void* lrelu_mask, hipStream_t st, bool in16, bool out16) {
+    if (prec == AGAN_PREC_F16) launch_gk<1>(in, wk, bias, dst, g, p, act, lrelu_mask, st, in16, out16);
+    else launch_gk<0>(in, wk, bias, dst, g, p, act, lrelu_mask, st, in16, out16);
+}
+
+}  // namespace conv
+}  // namespace agan

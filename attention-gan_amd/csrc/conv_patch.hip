@@ -456,6 +456,19 @@ __device__ __forceinline__ float buf_load_acc(u32x4 rsrc, unsigned voff, unsigne
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=a"(v) : "v"(voff), "s"(rsrc), "s"(soff));
     return v;
 }
+__device__ __forceinline__ float buf_load_acc16(u32x4 rsrc, unsigned voff, unsigned soff) {      // one 16-bit value, zero-extended
+    float v;
+    asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=a"(v) : "v"(voff), "s"(rsrc), "s"(soff));
+    return v;
+}
+// a staged value as fp32: fp32 storage as it stands; 16-bit storage (type ET) widened exactly
+template <int ET, bool S16>
+__device__ __forceinline__ float staged_f32(float v) {
+    if (!S16) return v;
+    const unsigned u = __float_as_uint(v);
+    if (ET == 0) return __uint_as_float(u << 16);
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)u);
+}
 __device__ __forceinline__ void staged_wait(float (&v)[8]) {       // all staged loads have landed; ties the 8 values to the wait
     asm volatile("s_waitcnt vmcnt(0)" : "+a"(v[0]), "+a"(v[1]), "+a"(v[2]), "+a"(v[3]), "+a"(v[4]), "+a"(v[5]), "+a"(v[6]), "+a"(v[7]));
 }
@@ -474,8 +487,9 @@ template <int BJ> struct WgCfg {
     static constexpr int kYItems = 128 * (BJ / 8) / 256;      // (pixel, cout octet) staging items per thread
 };
 
-template <int ET, int NPL, int BJ, int NT>
-__global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dst,
+// X16 / Y16: x / dy are stored in the 16-bit type of ET instead of fp32 (include/agan.h: AGAN_DT_*; one-plane modes only)
+template <int ET, int NPL, int BJ, int NT, bool X16 = false, bool Y16 = false>
+__global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
                                                                const Geom g, const PatchPlan pp, const int psplit, const int tiles_per_split,
                                                                const size_t slab, const float* __restrict__ x_scale,
                                                                const float* __restrict__ dy_scale) {
@@ -514,8 +528,10 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
     const int twl = pp.twl, thl = pp.thl;
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     const int by = pp.base_y[py][ph >> 1], bx = pp.base_x[px][ph & 1];
-    const u32x4 rx = make_rsrc4(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
-    const u32x4 rdy = make_rsrc4(dy, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    static_assert(!(X16 || Y16) || NPL == 1, "16-bit activation storage goes with the one-plane modes");
+    constexpr unsigned XE = X16 ? 2u : 4u, YE = Y16 ? 2u : 4u;      // bytes per stored element
+    const u32x4 rx = make_rsrc4(x, (size_t)g.B * g.Cin * ihw * XE);
+    const u32x4 rdy = make_rsrc4(dy, (size_t)g.B * g.Cout * ohw * YE);
     const int tile_beg = split * tiles_per_split, tile_end = min(pp.mtiles, tile_beg + tiles_per_split);
 
     // ---- staging items (tile independent parts) ----
@@ -547,10 +563,12 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
                 const int b = tb0 + xi_b[i];
                 const int iy = pp.IS * (ty0 + xi_j[i]) + by, ix = pp.IS * (tx0 + xi_i[i]) + bx;
                 const bool ok = (xi_oct[i] < kCH / 8) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-                const unsigned voff = ok ? (unsigned)((b * g.Cin + c0 + xi_oct[i] * 8) * ihw + iy * g.IW + ix) * 4u : kOOB;
+                const unsigned voff = ok ? (unsigned)((b * g.Cin + c0 + xi_oct[i] * 8) * ihw + iy * g.IW + ix) * XE : kOOB;
                 const int nrem = g.Cin - c0 - xi_oct[i] * 8;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) xr[i][c] = buf_load_acc(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * 4u);
+                for (int c = 0; c < 8; ++c)
+                    xr[i][c] = X16 ? buf_load_acc16(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * XE)
+                                   : buf_load_acc(rx, c < nrem ? voff : kOOB, (unsigned)(c * ihw) * XE);
             }
         }
         constexpr int kYFirst = 2;                      // dy items that ride with part 0
@@ -564,10 +582,12 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
                 const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
                 const bool ok = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
                 const int n = j0 + oct * 8;
-                const unsigned voff = ok ? (unsigned)((b * g.Cout + n) * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * 4u : kOOB;
+                const unsigned voff = ok ? (unsigned)((b * g.Cout + n) * ohw + (yq * g.OS + py) * g.OW + (xq * g.OS + px)) * YE : kOOB;
                 const int nrem = g.Cout - n;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) yr[i][c] = buf_load_acc(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * 4u);
+                for (int c = 0; c < 8; ++c)
+                    yr[i][c] = Y16 ? buf_load_acc16(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * YE)
+                                   : buf_load_acc(rdy, c < nrem ? voff : kOOB, (unsigned)(c * ohw) * YE);
             }
         }
     };
@@ -584,7 +604,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
                 for (int c = 0; c < 4; ++c) {
                     unsigned pl[NPL];
                     if (SCALED) split_pack2<ET, NPL>(xr[i][2 * c] * xsc, xr[i][2 * c + 1] * xsc, pl);
-                    else split_pack2<ET, NPL>(xr[i][2 * c], xr[i][2 * c + 1], pl);
+                    else split_pack2<ET, NPL>(staged_f32<ET, X16>(xr[i][2 * c]), staged_f32<ET, X16>(xr[i][2 * c + 1]), pl);
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
                 }
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const float* __re
             for (int c = 0; c < 4; ++c) {
                 unsigned pl[NPL];
                 if (SCALED) split_pack2<ET, NPL>(yr[i][2 * c] * ysc, yr[i][2 * c + 1] * ysc, pl);
-                else split_pack2<ET, NPL>(yr[i][2 * c], yr[i][2 * c + 1], pl);
+                else split_pack2<ET, NPL>(staged_f32<ET, Y16>(yr[i][2 * c]), staged_f32<ET, Y16>(yr[i][2 * c + 1]), pl);
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) v[q][c] = pl[q];
             }
@@ -987,14 +1007,23 @@ void launch_bn(const float* in, const void* wk, const float* bias, float* dst, c
     else launch_nt<ET, NPL, 32>(in, wk, bias, dst, g, pp, p, act, mask, st, in_scale, out_amax);
 }
 
-template <int ET, int NPL, int BJ>
-void launch_wg_nt(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st,
+template <int ET, int NPL, int BJ, bool X16 = false, bool Y16 = false>
+void launch_wg_nt(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st,
                   const float* xs = nullptr, const float* ys = nullptr) {
     dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
     if (pp.NT == 9)
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
     else
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
+}
+// one-plane modes with typed activation storage
+template <int ET, int BJ>
+void launch_wg_dt(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st, bool x16,
+                  bool y16) {
+    if (x16 && y16) launch_wg_nt<ET, 1, BJ, true, true>(x, dy, part, g, pp, p, st);
+    else if (x16) launch_wg_nt<ET, 1, BJ, true, false>(x, dy, part, g, pp, p, st);
+    else if (y16) launch_wg_nt<ET, 1, BJ, false, true>(x, dy, part, g, pp, p, st);
+    else launch_wg_nt<ET, 1, BJ>(x, dy, part, g, pp, p, st);
 }
 
 inline int pow2ceil_log(int v) {
@@ -1201,8 +1230,13 @@ PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec) {
     return p;
 }
 
-void launch_patch_wgrad(const float* x, const float* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
-                        hipStream_t st, const float* x_scale, const float* dy_scale) {
+void launch_patch_wgrad(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
+                        hipStream_t st, const float* x_scale, const float* dy_scale, bool x16, bool y16) {
+    if (x16 || y16) {          // (the caller has checked: one-plane mode, storage type = operand type)
+        if (prec == AGAN_PREC_BF16) { if (p.bj == 128) launch_wg_dt<0, 128>(x, dy, part, g, pp, p, st, x16, y16); else launch_wg_dt<0, 64>(x, dy, part, g, pp, p, st, x16, y16); }
+        else { if (p.bj == 128) launch_wg_dt<1, 128>(x, dy, part, g, pp, p, st, x16, y16); else launch_wg_dt<1, 64>(x, dy, part, g, pp, p, st, x16, y16); }
+        return;
+    }
     switch (prec) {
         case AGAN_PREC_F16X3: if (p.bj == 128) launch_wg_nt<1, 2, 128>(x, dy, part, g, pp, p, st, x_scale, dy_scale); else launch_wg_nt<1, 2, 64>(x, dy, part, g, pp, p, st, x_scale, dy_scale); break;
         case AGAN_PREC_BF16: if (p.bj == 128) launch_wg_nt<0, 1, 128>(x, dy, part, g, pp, p, st); else launch_wg_nt<0, 1, 64>(x, dy, part, g, pp, p, st); break;

@@ -33,6 +33,7 @@ GF, DF, EMB, COND, Z, T = 32, 64, 256, 100, 100, 10
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0}
 # what the conv engine multiplies in, per --precision (fp32 storage and fp32 accumulate in every mode)
 MFMA_PRODUCTS = {"f32": 1, "bf16": 1, "f16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
+MFMA_PLANES = {"f32": 1, "bf16": 1, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 2}      # 16-bit planes of a packed weight
 DTYPE_NOTE = {"f32": "f32", "bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3", "bf16x6": "bf16x6", "f16x3": "f16x3"}
 
 
@@ -65,7 +66,7 @@ class ConvTimer:
         self.lib.call("agan_timer_create", ctypes.byref(e))
         return e
 
-    def begin(self, kind, phase, g):
+    def begin(self, kind, phase, g, in_esz=4, out_esz=4):
         if not self.enabled:
             return
         K = g.Cin * g.R * g.S
@@ -78,8 +79,13 @@ class ConvTimer:
             tile = "small_n"
         wmode = "f32" if self.mode == "bf16x6" else self.mode      # bf16x6 weight gradients run on the fp32 MFMA kernels
         name = f"conv_wgrad_{wmode}" if phase == "wgrad" else f"conv_gather_{self.mode}_{tile}"
-        # algorithmic HBM bytes of this call: gathered tensor + produced tensor + weights, each moved once (fp32)
-        nbytes = 4.0 * (g.B * g.Cin * g.IH * g.IW + g.B * g.Cout * g.OH * g.OW + g.Cout * K * (g.OS * g.OS))
+        # algorithmic HBM bytes of this call: gathered tensor + produced tensor + weights, each moved once, in the storage types of
+        # this call (fp32, or 16 bits under --storage; a weight gradient reads both activations and writes fp32 weights)
+        if phase == "wgrad":
+            nbytes = in_esz * g.B * g.Cin * g.IH * g.IW + out_esz * g.B * g.Cout * g.OH * g.OW + 4.0 * g.Cout * K * (g.OS * g.OS)
+        else:
+            wesz = 4.0 if self.mode == "f32" else 2.0 * MFMA_PLANES.get(self.mode, 1)
+            nbytes = in_esz * g.B * g.Cin * g.IH * g.IW + out_esz * g.B * g.Cout * g.OH * g.OW + wesz * g.Cout * K * (g.OS * g.OS)
         e0, e1 = self._event(), self._event()
         self.lib.call("agan_timer_arm", e0, e1)
         self.records.append((name, algorithmic, executed, nbytes, e0, e1))
@@ -253,7 +259,11 @@ def side_measurements(args, dev, HF, LIB, step, words, sent, reals):
         HF.set_precision(LIB.PRECISIONS[other])
         try:
             out[f"precision_{other}"] = rate(lambda: step.step(words, sent, lens_full, None, reals))
+            if other == "bf16" and args.storage == "f32":
+                HF.set_activation_storage("bf16")
+                out["precision_bf16_storage_bf16"] = rate(lambda: step.step(words, sent, lens_full, None, reals))
         finally:
+            HF.set_activation_storage(None if args.storage == "f32" else args.storage)
             HF.set_precision(LIB.PRECISIONS[args.precision])
     try:
         RNN = importlib.import_module("attention-gan_amd.networks.rnn_encoder")
@@ -283,6 +293,10 @@ def main():
                     help="MFMA mode of the conv engine: f32 = exact fp32 products (v_mfma_f32_32x32x2_f32); bf16x6 = three bf16 planes, "
                          "6 MFMAs per product (fp32-grade); bf16x3 = two planes, 3 MFMAs; bf16 / f16 = operands rounded to 16 bits "
                          "(BASELINE configs[1] / configs[4] arithmetic)")
+    ap.add_argument("--storage", choices=["f32", "bf16", "f16"], default="f32",
+                    help="storage type of activations in HBM: f32 (the reference's layout, default) or the operand type of the one-plane "
+                         "16-bit modes (--precision bf16 --storage bf16 / --precision f16 --storage f16): conv outputs, BatchNorm "
+                         "inputs / outputs and their gradients are rounded once when stored and gathered without conversion")
     ap.add_argument("--image-encoder", choices=["standin", "inception"], default="standin",
                     help="frozen DAMSM image encoder plug-in: 'standin' = contract-only stub (SURVEY §8d prices the hot path without "
                          "the third-party trunk); 'inception' = Inception-v3-shaped trunk on stock MIOpen convs, random weights")
@@ -335,6 +349,10 @@ def main():
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     LIB = importlib.import_module("attention-gan_amd.backend.lib")
     HF.set_precision(LIB.PRECISIONS[args.precision])
+    if args.storage != "f32":
+        if args.storage != args.precision:
+            raise SystemExit(f"--storage {args.storage} needs --precision {args.storage} (the storage type is the MFMA operand type)")
+        HF.set_activation_storage(args.storage)
     step = build(dev, args.batch, HF, args.image_encoder)
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
     timer = ConvTimer(importlib.import_module("attention-gan_amd.backend.lib"), args.precision)
@@ -447,6 +465,7 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
+            "activation_storage": args.storage,
             "config": {"workload": "full 3-stage AttnGAN 64->128->256 train step: G + 3xD updates + word attention + DAMSM words/sentence "
                                    "loss + KL + 4x fused Adam (BASELINE.json configs[2])",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "gf_dim": GF, "df_dim": DF, "emb_dim": EMB,

@@ -51,6 +51,13 @@ enum {
  * heads) runs in AGAN_PREC_F32 whatever mode is asked for.  agan_conv_effective_prec says which one a geometry gets -- pack the
  * weights for THAT precision (declared below, after agan_conv_geom). */
 
+/* Storage type of an ACTIVATION tensor in HBM (round 3).  fp32 is the reference's layout and the default everywhere.  The
+ * one-plane 16-bit modes can also keep activations in their operand type -- AGAN_DT_BF16 with AGAN_PREC_BF16, AGAN_DT_F16 with
+ * AGAN_PREC_F16 -- through the `*_dt` entry points below: conv outputs, BatchNorm inputs/outputs and their gradients are then
+ * rounded ONCE to 16 bits when they are stored, the gathers load 16-bit values without converting, and half the bytes move.
+ * BatchNorm statistics, softmax, losses, weight gradients, master weights and the optimiser stay fp32/fp64 in every mode. */
+enum { AGAN_DT_F32 = 0, AGAN_DT_BF16 = 1, AGAN_DT_F16 = 2 };
+
 int agan_version(void);
 const char* agan_last_error(void);
 
@@ -128,6 +135,15 @@ int agan_conv_gather(const float* in, const void* wk, const float* bias, float* 
                      const float* in_amax /* AGAN_PREC_F16X3: amax slot of `in`; NULL otherwise */,
                      float* out_amax /* optional: amax slot that receives max|out| (16-bit MFMA paths) */);
 
+/* The same call with typed activation storage: `in` has in_dtype, `out` and `lrelu_mask` have out_dtype (AGAN_DT_*).  16-bit
+ * tensors need prec == AGAN_PREC_BF16 (AGAN_DT_BF16) / AGAN_PREC_F16 (AGAN_DT_F16) and a geometry the row-block gather
+ * (csrc/conv_p16.hip) takes: agan_conv_gather_dt_supported says so (1 / 0) -- a caller converts around an unsupported layer.
+ * With both dtypes AGAN_DT_F32 this IS agan_conv_gather (workspace: agan_conv_gather_ws_bytes in every case). */
+int agan_conv_gather_dt_supported(const agan_conv_geom* g, int prec, int in_dtype, int out_dtype);
+int agan_conv_gather_dt(const void* in, const void* wk, const float* bias, void* out, const agan_conv_geom* g,
+                        const int32_t* ktable, int prec, int act, const void* lrelu_mask, void* ws, size_t ws_bytes, void* stream,
+                        const float* in_amax, float* out_amax, int in_dtype, int out_dtype);
+
 /* amax slots (AGAN_PREC_F16X3).  The fp16 split mode scales each gathered operand by the power of two that lands its largest
  * magnitude in (2^12, 2^13]; the kernels derive that scale themselves from an AMAX SLOT: AGAN_AMAX_SLOT floats of device memory,
  * ZEROED by the caller, into which the kernel that PRODUCES a tensor folds max|value| (the `*_amax` arguments of the BatchNorm
@@ -144,6 +160,13 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
                     int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream,
                     const float* x_amax, const float* dy_amax /* AGAN_PREC_F16X3: amax slots of x and dy; NULL otherwise */);
+
+/* the same with typed activation storage (x: x_dtype, dy: dy_dtype; dw stays fp32): 16-bit tensors where
+ * agan_conv_wgrad_dt_supported says 1 -- the one-plane patch weight gradient of the matching precision mode */
+int agan_conv_wgrad_dt_supported(const agan_conv_geom* g, int pack_mode, int prec, int x_dtype, int dy_dtype);
+int agan_conv_wgrad_dt(const void* x, const void* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
+                       int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                       const float* x_amax, const float* dy_amax, int x_dtype, int dy_dtype);
 
 /* dbias[n] = sum_{b,y,x} dy[b,n,y,x]  (bias of nn.Linear / outlogits conv: generator_submodules.py:152, discriminators.py:15) */
 int agan_bias_grad(const float* dy, float* dbias, int B, int C, int HW, int accumulate, void* stream);
@@ -178,6 +201,23 @@ size_t agan_bn_act_bwd_ws_bytes(int B, int C, int HW);
 int agan_bn_act_bwd(const float* x, const float* dout, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
                     int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax);
+/* The same three calls with typed activation storage (AGAN_DT_*): x and dx have x_dtype; out, dout and the residual have
+ * out_dtype.  Combinations: (F32, F32) = the calls above; (BF16, BF16), (F16, F16); (F32, BF16), (F32, F16) for a layer whose conv
+ * ran on an fp32-storage kernel.  Statistics, gamma / beta and their gradients stay fp32 (sums in fp64).  [B, C] inputs
+ * (BatchNorm1d) are fp32 only. */
+int agan_bn_stats_dt(const void* x, int B, int C, int HW, float eps, float* mean, float* invstd, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float momentum, void* ws, size_t ws_bytes, void* stream,
+                     int x_dtype);
+int agan_bn_act_fwd_dt(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const void* residual, void* out, int B, int C, int HW, int act, void* stream, float* out_amax, int x_dtype,
+                       int out_dtype);
+int agan_bn_train_fwd_dt(const void* x, const float* gamma, const float* beta, const void* residual, void* out, float* mean,
+                         float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, int HW,
+                         float eps, float momentum, int act, int groups, void* ws, size_t ws_bytes, void* stream, float* out_amax,
+                         int x_dtype, int out_dtype);
+int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, void* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act, int accumulate,
+                       int groups, void* ws, size_t ws_bytes, void* stream, float* dx_amax, int x_dtype, int out_dtype);
 /* plain activations without BN (first D conv + LeakyReLU layers.py:139-140; tanh generator_submodules.py:137) */
 int agan_act_fwd(const float* x, float* out, size_t n, int act, void* stream);
 int agan_act_bwd(const float* out, const float* dout, float* dx, size_t n, int act, void* stream);

@@ -255,8 +255,12 @@ def _l2(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-def test_config1_stage1_batch64_bf16():
-    """BASELINE.json configs[1] AS WRITTEN: stage-1 only (CA-net + gen1 + img_out1 + Disc64) at the real widths (gf 32, df 64,
+@pytest.mark.parametrize("storage", ["f32-storage", "bf16-storage"])
+def test_config1_stage1_batch64_bf16(storage):
+    """[bf16-storage]: the same stage with conv outputs, BatchNorm inputs / outputs and their gradients STORED in bf16
+    (HF.set_activation_storage; include/agan.h AGAN_DT_BF16): one more rounding per stored tensor, same bounds.
+
+    BASELINE.json configs[1] AS WRITTEN: stage-1 only (CA-net + gen1 + img_out1 + Disc64) at the real widths (gf 32, df 64,
     emb 256, z = cond = 100), batch 64, conv operands rounded to bf16 (AGAN_PREC_BF16: v_mfma_f32_32x32x16_bf16, fp32
     accumulate; BatchNorm statistics, GLU, losses and every tensor in HBM stay fp32), against the fp32 CPU oracle.
 
@@ -292,6 +296,7 @@ def test_config1_stage1_batch64_bf16():
     ggrads_ref = dict(zip(gkeys, torch.autograd.grad(gloss_ref, [gp[k] for k in gkeys])))
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     HF.set_precision(L.PREC_BF16)
+    HF.set_activation_storage("bf16" if storage == "bf16-storage" else None)
     try:
         cond, mu_d, lv_d = G.vae(sent.to(DEV), eps.to(DEV))
         img = G.img_out1(G.gen1(noise.to(DEV), cond))
@@ -303,12 +308,13 @@ def test_config1_stage1_batch64_bf16():
         gloss = GL.get_loss(D, img) + KL(mu_d, lv_d)
         gloss.backward()
     finally:
+        HF.set_activation_storage(None)
         HF.set_precision(L.PREC_F32)
     e_img = float((img.detach().cpu() - img_ref.detach()).abs().max() / img_ref.detach().abs().max())
     named = dict(G.named_parameters())
     wg = max(_l2(named[k].grad, ggrads_ref[k]) for k in gkeys)
     wd = max(_l2(dgr[k], dgrads_ref[k]) for k in dkeys)
-    print(f"configs[1] bf16 B=64: image max-rel {e_img:.2e} | d_loss {float(dloss):.5f} vs {float(dloss_ref):.5f} | g_loss {float(gloss):.5f} vs "
+    print(f"configs[1] bf16 B=64 [{storage}]: image max-rel {e_img:.2e} | d_loss {float(dloss):.5f} vs {float(dloss_ref):.5f} | g_loss {float(gloss):.5f} vs "
           f"{float(gloss_ref):.5f} | worst G grad L2 {wg:.2e} | worst D grad L2 {wd:.2e}")
     assert e_img <= 3e-2
     assert abs(float(dloss) - float(dloss_ref)) <= 3e-2 * max(1.0, abs(float(dloss_ref)))
