@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
     constexpr int PB = CHS * 2 + 16;                 // LDS bytes per position: an odd multiple of 16 B (conflict-free b128 rows)
     constexpr int PXB = IN16 ? 8 : 4;                // pixels per 16-byte load
     constexpr int ESZ = IN16 ? 2 : 4;
-    constexpr int WD = SPS == 18 ? 9 : 8;            // weight ring depth (divides SPS)
+    // Weight ring depth (divides SPS).  Loads return IN ORDER, so a weight fragment issued after the patch loads of a stage cannot land
+    // before them: the ring depth is therefore also the number of k-steps the patch loads get before anything waits on them.
+    // (measured, round 3: a ring as deep as the whole stage -- 64-72 VGPRs -- was 0-25 % SLOWER than 8-9 k-steps: the kernel is bound
+    // by the texture-address path, 57 % busy, of which the weight fragments are two thirds, not by one exposed latency)
+#ifndef AGAN_P16_WD_FULL
+#define AGAN_P16_WD_FULL 0
+#endif
+    constexpr int WD = (AGAN_P16_WD_FULL && NI == 1) ? SPS : (SPS == 18 ? 9 : 8);
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
     constexpr int NWR = NI * PXB;                    // LDS item writes per thread and stage
     constexpr int U0 = SPS / 2;                      // first k-step that carries item writes: the loads get SPS/2 k-steps to land

@@ -1,13 +1,18 @@
 #!/bin/bash
-# usage: bash profiles/collect_evidence.sh MODE   (on the GPU box, from the repo root; writes gpurun_out/r02_${MODE}_*: copy those into profiles/)
+# usage: bash profiles/collect_evidence.sh MODE [STORAGE] [TAG]   (on the GPU box, from the repo root)
+#   MODE = --precision of bench.py, STORAGE = --storage (default f32), TAG = file prefix (default r03_${MODE}[_s16])
+#   writes gpurun_out/${TAG}_*: copy those into profiles/
 MODE=$1
+STORAGE=${2:-f32}
+if [ "$STORAGE" = "f32" ]; then DEF=r03_${MODE}; else DEF=r03_${MODE}_s16; fi
+TAG=${3:-$DEF}
 R=$GRAFT_REPO_ROOT
 case $MODE in f16*) LOWC=SQ_INSTS_VALU_MFMA_MOPS_F16;; *) LOWC=SQ_INSTS_VALU_MFMA_MOPS_BF16;; esac
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${MODE}_stats -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_mfma -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_fetch -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${MODE}_write -o p -- $B > /dev/null 2>&1 &&
-cd $R && python3 profiles/make_counters.py gpurun_out/ev_${MODE} gpurun_out r02_${MODE} > gpurun_out/ev_${MODE}_summary.txt 2>&1
-tail -3 gpurun_out/ev_${MODE}_summary.txt
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE --storage $STORAGE"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${TAG}_stats -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_mfma -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_fetch -o p -- $B > /dev/null 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_write -o p -- $B > /dev/null 2>&1 &&
+cd $R && python3 profiles/make_counters.py gpurun_out/ev_${TAG} gpurun_out ${TAG} > gpurun_out/ev_${TAG}_summary.txt 2>&1
+tail -3 gpurun_out/ev_${TAG}_summary.txt

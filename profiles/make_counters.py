@@ -31,6 +31,10 @@ import shutil
 import sys
 
 FAMILIES = [  # (family, substrings any of which selects the kernel)
+    # row-block gather (conv_p16.hip), by geometry kind = 2nd template argument: <ET, GK, BN, IN16, OUT16, NI>
+    ("conv_p16 4x4-s2 gather (D forward convs; upsample-conv dgrad)", ["conv_p16_kernel<0, 2,", "conv_p16_kernel<1, 2,"]),
+    ("conv_p16 2x2-class gather (D conv dgrad; upsample-conv fwd)", ["conv_p16_kernel<0, 1,", "conv_p16_kernel<1, 1,"]),
+    ("conv_p16 3x3 gather (G ResBlock / D Block3x3 fwd + dgrad)", ["conv_p16_kernel<0, 0,", "conv_p16_kernel<1, 0,"]),
     ("conv_gather_patch16 (fwd/dgrad, 16-bit MFMA)", ["conv_patch_kernel"]),
     ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
