@@ -291,6 +291,7 @@ struct P16Plan {
     int nstages, wsteps;                // stages (CHS-channel chunks); k-steps of the packed weights per class
     int bn, ntiles, ncls, ksplit, stages_per_split;
     int buf_bytes;                      // one LDS patch buffer (the kernel holds two)
+    int lds_epi;                        // 16-bit output leaves through LDS as 16-byte stores
     size_t slab, ws_bytes;
     FastDiv dNXB, dPH, dTB;
 };

@@ -266,6 +266,38 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
     const int nw = n0 + wn * 32;
     const bool nfull = nw + 32 <= g.Cout;
     const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : static_cast<const float*>(out), (size_t)g.Cout * sizeof(float));
+    if (OUT16 && pp.lds_epi && !split_out && !masked) {
+        // 16-bit output, unit-stride lattice: the tile goes through LDS (free after the K loop's last barrier) as [cout][128 pixels] and
+        // leaves as 16-BYTE stores of 8 consecutive pixels -- 8 store instructions per wave instead of 64 two-byte ones (the kernel is
+        // bound by its vector-memory instruction count: texture-address path 57 % busy, round-3 PMC)
+        constexpr int ROWB = 272;                          // bytes per cout row: 128 x 2 + 16 (rows 4 apart land 16 banks apart)
+        unsigned short* const l16 = reinterpret_cast<unsigned short*>(lds);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int pcol = (wm * TM + t) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nr = (r & 3) + 8 * (r >> 2);
+                float v = acc[t][r];
+                if (add_bias) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
+                if (lrelu) v = v > 0.f ? v : 0.2f * v;
+                l16[(wn * 32 + nr + 4 * lh) * (ROWB / 2) + pcol] = (unsigned short)(pack2<ET>(v, 0.f) & 0xFFFFu);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BN * 16 / 256; ++i) {
+            const int c = tid + i * 256;
+            const int n = c >> 4, l = (c & 15) * 8;
+            const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+            const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+            const bool ok = (b < g.B) & (yq < g.OH) & (xq < g.OW) & (n0 + n < g.Cout);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + n * ROWB + (c & 15) * 16);
+            const unsigned vo = ok ? (unsigned)(((b * g.Cout + n0 + n) * g.OH + yq) * g.OW + xq) * 2u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo, 0, 0);
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int l = (wm * TM + t) * 32 + l31;
@@ -393,6 +425,8 @@ P16Plan plan_p16(const Geom& g, bool in16) {
     p.ksplit = cdiv(p.nstages, p.stages_per_split);
     p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
     p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
+    // LDS-staged 16-byte output stores (16-bit output only): unit-stride lattice, rows of whole 8-pixel chunks, room for [bn][136] x 2 B
+    p.lds_epi = (g.OS == 1 && p.twl >= 3 && (g.OW & 7) == 0 && 2 * p.buf_bytes >= p.bn * 272) ? 1 : 0;
     p.dNXB = make_fastdiv((unsigned)p.NXB);
     p.dPH = make_fastdiv((unsigned)p.PH);
     p.dTB = make_fastdiv((unsigned)p.TB);
