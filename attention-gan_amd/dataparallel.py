@@ -201,6 +201,32 @@ class GradBuckets:
         else:
             self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def exchange_all(self) -> float:
+        """Exchange EVERY bucket now, after the backward has completed on the current stream (no hooks, no overlap with this
+        optimiser's own backward): the form the segment-wise captured step uses between its graphs (GanTrainStep.capture_segments),
+        where the backward is a replayed HIP graph and Python hooks never run.  The collectives go out on the comm stream in bucket
+        order; the current stream waits for them.  Returns the scale the optimiser must apply (1/world_size)."""
+        if not self.active:
+            return 1.0
+        cur = torch.cuda.current_stream() if self.opt.flat.is_cuda else None
+        handles = []
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(cur)
+        for s, e in self.bounds:
+            chunk = self.opt.grad[s:e]
+            if self.direct is not None:
+                self.direct.all_reduce_(chunk, self.comm_stream)
+            elif self.comm_stream is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()
+        if self.comm_stream is not None:
+            cur.wait_stream(self.comm_stream)
+        return 1.0 / self.world
+
     def finish(self) -> float:
         """Join outstanding exchanges; returns the scale the optimiser must apply (1/world_size)."""
         if not self.active:

@@ -287,6 +287,111 @@ class GanTrainStep(ModelTrainer):
             out = self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
         return GraphedStep(graph, out)
 
+    # -- segment-wise HIP graphs for world > 1 --------------------------------------------------------------------------
+    def capture_segments(self, word_embs: Tensor, sent_embs: Tensor, lengths: Tensor, real_imgs: Sequence[Tensor], warmup: int = 2,
+                         noise: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> "SegmentedStep":
+        """The train step as NINE HIP graphs with the gradient exchange launched between them -- the form for world_size > 1, where
+        the whole-step graph of capture() cannot be used (the RCCL collectives are not captured) and an eager step costs every rank
+        ~11 ms of Python per 27 ms step on host cores the 8 ranks share:
+
+            [G forward]  ->  per discriminator, largest first, each on its own stream:
+                                 [D_i forward + backward]  -> all-reduce of D_i's flat gradient  ->  [Adam D_i]
+                         ->  [G update: forward through the three D, DAMSM, KL, backward]  -> all-reduce of G's gradient  ->  [Adam G]
+
+        A discriminator's exchange is issued when ITS backward graph has finished (not bucket by bucket inside it, as the eager
+        step's hooks do), so it overlaps the backward graphs of the OTHER discriminators -- the largest (Disc256, 273 MB) goes
+        first -- and nothing overlaps the generator's 28 MB.  The arguments become static input buffers exactly as for capture();
+        the graphs share one memory pool and must be replayed in capture order (SegmentedStep.replay does).  Results are
+        bit-identical to the eager step (tests/test_gpu_dataparallel.py, one-rank `nccl` rehearsal)."""
+        if not (isinstance(lengths, Tensor) and lengths.is_cuda and lengths.dtype == torch.int64):
+            raise ValueError("capture_segments(): lengths must be an int64 device tensor")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream: tables, caches, allocator pools
+            for _ in range(max(1, warmup)):
+                self.step(word_embs, sent_embs, lengths, None, real_imgs, noise, eps)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        HF.build_pack_tables()
+        pool = torch.cuda.graph_pool_handle()
+        dev = word_embs.device
+        n = len(self.Ds)
+        seg = SegmentedStep(self)
+        b = word_embs.shape[0]
+        buckets = [self.g_buckets] + self.d_buckets
+        armed = [bk._armed for bk in buckets]
+        for bk in buckets:
+            bk._armed = False                              # no hook-driven collectives inside a capture
+        prev_side = HF.set_wgrad_side_stream(False)
+        try:
+            # ---- generator forward ----
+            g0 = torch.cuda.CUDAGraph()
+            if self.rng.device.type == "cuda":
+                g0.register_generator_state(self.rng)
+            with torch.cuda.graph(g0, pool=pool):
+                HF.amax_begin_step(dev)
+                labels = self._make_match_labels(b)
+                mask = self._make_mask(lengths, word_embs.shape[2])
+                z = noise if noise is not None else torch.randn(b, self.G.z_dim, dtype=torch.float32, device=dev, generator=self.rng)
+                e = eps if eps is not None else torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=dev, generator=self.rng)
+                fakes, attn, mu, logvar = self.G(z, sent_embs, word_embs, mask, e)
+            seg.gen_forward = g0
+            out: Dict[str, Tensor] = {}
+            # ---- discriminator updates: backward graph, (exchange), Adam graph ----
+            for i in self.d_order:
+                d, opt = self.Ds[i], self.d_opts[i]
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=pool):
+                    opt.zero_grad()
+                    loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
+                    loss.backward()
+                    opt.join_and_rebind()
+                    out[f"d_loss{i}"] = loss.detach()
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool):
+                    opt.step(1.0 / self.d_buckets[i].world if self.d_buckets[i].active else 1.0)
+                seg.d_backward[i], seg.d_adam[i] = gb, ga
+            # ---- generator update ----
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, pool=pool):
+                self.g_opt.zero_grad()
+                for d in self.Ds:
+                    d.requires_grad_(False)
+                terms = []
+                for i, d in enumerate(self.Ds):
+                    gl = self.gen_loss.get_loss(d, fakes[i])
+                    terms.append(gl)
+                    out[f"g_loss{i}"] = gl.detach()
+                    if i == n - 1 and self.image_encoder is not None:
+                        regions, code = self.image_encoder(fakes[i])
+                        wl, _ = self.words_loss.get_loss(regions, word_embs, labels, lengths, None)
+                        sl = self.sent_loss.get_loss(code, sent_embs, labels, None)
+                        terms += [wl, sl]
+                        out["w_loss"], out["s_loss"] = wl.detach(), sl.detach()
+                total = terms[0]
+                for t in terms[1:]:
+                    total = total + t
+                kl = KL_loss(mu, logvar)
+                total = total + kl
+                out["kl"], out["g_total"] = kl.detach(), total.detach()
+                total.backward()
+                for d in self.Ds:
+                    d.requires_grad_(True)
+                self.g_opt.join_and_rebind()
+            gadam = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gadam, pool=pool):
+                self.g_opt.step(1.0 / self.g_buckets.world if self.g_buckets.active else 1.0)
+            seg.g_backward, seg.g_adam = gg, gadam
+            out["fake_imgs"] = [f.detach() for f in fakes]
+            out["attn_maps"] = [a.detach() for a in attn]
+            out["mu"], out["logvar"] = mu.detach(), logvar.detach()
+            seg.out = out
+        finally:
+            HF.set_wgrad_side_stream(prev_side)
+            for bk, a in zip(buckets, armed):
+                bk._armed = a
+        return seg
+
     # -- checkpoint / resume (SURVEY.md §8f-3: the reference only saves, and its four `Adam` objects share one Adam.pkl) --
     def state_dict(self, all_ranks: bool = True) -> Dict:
         """Checkpoint of the whole step: weights, BatchNorm buffers, the four optimisers and the noise generators' states (so a
@@ -342,6 +447,37 @@ class GraphedStep:
 
     def replay(self) -> Dict[str, Tensor]:
         self.graph.replay()
+        return self.out
+
+
+class SegmentedStep:
+    """The graphs of GanTrainStep.capture_segments and the eager gradient exchange between them; `replay()` runs one train step."""
+
+    def __init__(self, trainer: "GanTrainStep"):
+        self.t = trainer
+        self.gen_forward = None
+        self.d_backward: Dict[int, object] = {}
+        self.d_adam: Dict[int, object] = {}
+        self.g_backward = self.g_adam = None
+        self.out: Dict[str, Tensor] = {}
+
+    def replay(self) -> Dict[str, Tensor]:
+        t = self.t
+        main = torch.cuda.current_stream()
+        self.gen_forward.replay()
+        streams = t._d_streams(len(t.Ds), next(t.G.parameters()).device)
+        for i in t.d_order:                                # largest discriminator first: its exchange travels under the others' graphs
+            st = streams[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self.d_backward[i].replay()
+                t.d_buckets[i].exchange_all()              # on the comm stream, behind this stream; this stream waits for it
+                self.d_adam[i].replay()
+        for st in streams:
+            main.wait_stream(st)
+        self.g_backward.replay()
+        t.g_buckets.exchange_all()
+        self.g_adam.replay()
         return self.out
 
 

@@ -300,9 +300,10 @@ def main():
     ap.add_argument("--image-encoder", choices=["standin", "inception"], default="standin",
                     help="frozen DAMSM image encoder plug-in: 'standin' = contract-only stub (SURVEY §8d prices the hot path without "
                          "the third-party trunk); 'inception' = Inception-v3-shaped trunk on stock MIOpen convs, random weights")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--graph", choices=["auto", "on", "off", "segments"], default="auto",
                     help="launch mode of the step: captured HIP graph replay or eager (auto: at 1 GPU probe both in the untimed warm-up and keep "
-                         "the faster; eager under torch.distributed)")
+                         "the faster; eager under torch.distributed).  segments = nine HIP graphs with the gradient exchange launched "
+                         "between them (GanTrainStep.capture_segments): the graph form that also works under torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short side measurements reported beside the headline (random caption lengths, the fp32-MFMA mode, "
@@ -398,6 +399,9 @@ def main():
                   file=sys.stderr, flush=True)
     elif not dp and args.graph == "on":
         graphed = step.capture(words, sent, lens_dev, reals, warmup=2)
+    elif args.graph == "segments":
+        graphed = step.capture_segments(words, sent, lens_dev, reals, warmup=2)
+        use_graph = True
     one_step = graphed.replay if use_graph else eager_step
 
     for _ in range(args.warmup):
@@ -472,7 +476,8 @@ def main():
                        "seq_len": T, "image_encoder": ("frozen stand-in plug-in (pool+projection): the timed step is the hot path of SURVEY §8d, which "
                                                        "prices the third-party trunk separately" if args.image_encoder == "standin" else
                                                        "frozen Inception-v3-shaped trunk (random weights) on stock MIOpen convs, fwd + dgrad in the timed step"),
-                       "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}", "launch": "hip-graph replay" if use_graph else "eager",
+                       "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}",
+                       "launch": ("hip-graph segments + eager gradient exchange" if args.graph == "segments" else "hip-graph replay") if use_graph else "eager",
                        "losses_finite": finite},
             "roofline": roofline,
         }

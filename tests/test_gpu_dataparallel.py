@@ -247,3 +247,61 @@ def test_one_rank_direct_rccl_exchange_is_identity():
     assert float(out["g_total"]) == g_total
     for k, v in G.state_dict().items():
         assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
+
+
+def _segmented_worker(port, q, force_dp):
+    """capture_segments(): nine HIP graphs with the gradient exchange launched eagerly between them (the launch form for
+    world > 1), here in a world of ONE `nccl` rank with the exchange machinery forced on -- or with no process group at all."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if force_dp:
+        os.environ["AGAN_DP_FORCE"] = "1"
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        G, Ds, enc = _nets(dev)
+        step = TR.GanTrainStep(G, Ds, enc, bucket_bytes=64 << 10)
+        assert step.g_buckets.active == bool(force_dp)
+        words, sent, lens, reals, noise, eps = _shard(0, dev)
+        lens_dev = torch.tensor(lens, dtype=torch.int64, device=dev)
+        seg = step.capture_segments(words, sent, lens_dev, reals, warmup=1, noise=noise, eps=eps)      # (the warm-up is step 1)
+        assert len(seg.d_backward) == 3 and len(seg.d_adam) == 3
+        for _ in range(2):
+            out = seg.replay()
+        torch.cuda.synchronize()
+        q.put(({k: v.detach().cpu().numpy() for k, v in G.state_dict().items()},
+               [{k: v.detach().cpu().numpy() for k, v in d.state_dict().items()} for d in Ds], float(out["g_total"]), float(out["d_loss2"])))
+    finally:
+        if force_dp:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force_dp", [True, False], ids=["one-rank-nccl", "no-process-group"])
+def test_segmented_graphs_equal_eager_steps(force_dp):
+    """Three train steps -- one eager (the capture's warm-up) + two replays of the segment graphs with the exchange between them --
+    land bit for bit where three plain eager steps land: the segmentation reorders nothing and the exchange (a SUM over one rank)
+    adds nothing.  With a process group this is the whole N > 1 launch path short of a second rank."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_segmented_worker, args=(free_port(), q, force_dp))
+    p.start()
+    g_sd, d_sds, g_total, d_loss2 = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    dev = torch.device("cuda", 0)
+    G, Ds, enc = _nets(dev)
+    step = TR.GanTrainStep(G, Ds, enc)
+    words, sent, lens, reals, noise, eps = _shard(0, dev)
+    for _ in range(3):
+        out = step.step(words, sent, lens, None, reals, noise, eps)
+    torch.cuda.synchronize()
+    assert float(out["g_total"]) == g_total and float(out["d_loss2"]) == d_loss2
+    for k, v in G.state_dict().items():
+        assert np.array_equal(v.detach().cpu().numpy(), g_sd[k]), k
+    for d, sd in zip(Ds, d_sds):
+        for k, v in d.state_dict().items():
+            assert np.array_equal(v.detach().cpu().numpy(), sd[k]), k
