@@ -101,7 +101,7 @@ class DirectRccl:
         L.call("agan_comm_init", ctypes.byref(self.comm), rank, world, self._id)
         # ONE stream for every collective of this communicator (the generator's and the three discriminators' buckets): RCCL orders
         # the operations of a communicator by issue order, and one stream makes that order explicit on the device as well
-        self.stream = torch.cuda.Stream(priority=-1)
+        self.stream = torch.cuda.Stream(priority=int(os.environ.get("AGAN_DP_COMM_PRIO", "0")))     # (normal priority: see GradBuckets)
 
     @classmethod
     def get(cls, group=None):
@@ -163,9 +163,17 @@ class GradBuckets:
             if self.direct is not None:
                 self.comm_stream = self.direct.stream
             elif opt.flat.is_cuda:
-                self.comm_stream = torch.cuda.Stream(device=opt.flat.device, priority=-1)      # ahead of the chip-filling compute kernels
-            for i, p in enumerate(opt.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                # NORMAL priority (AGAN_DP_COMM_PRIO overrides).  Round 2 made this a high-priority stream "ahead of the chip-filling
+                # compute kernels"; measured in round 3 (profiles/r03_dp_rehearsal.txt): on this ROCm stack a priority -1 stream that
+                # merely takes part in the event waits between the three discriminator streams costs the step 16 ms (42.9 vs 26.7 ms,
+                # even with the collective itself stubbed out) -- cross-priority waits serialise the hardware queues.  At normal
+                # priority the whole exchange machinery costs 1.0-1.4 ms per step in the one-rank rehearsal.
+                self.comm_stream = torch.cuda.Stream(device=opt.flat.device, priority=int(os.environ.get("AGAN_DP_COMM_PRIO", "0")))
+            # AGAN_DP_NO_HOOKS=1: no per-parameter hooks -- every bucket is exchanged in finish(), after the whole backward (no overlap
+            # with this optimiser's own backward; the other optimisers' work still overlaps it)
+            if os.environ.get("AGAN_DP_NO_HOOKS") != "1":
+                for i, p in enumerate(opt.params):
+                    p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def arm(self) -> None:
         """Call before the backward whose gradients should be exchanged (after zero_grad)."""
@@ -195,6 +203,8 @@ class GradBuckets:
             if self.direct is not None:
                 chunk.record_stream(self.comm_stream)
                 self.direct.all_reduce_(chunk, self.comm_stream)      # joined in finish() through the comm stream
+                return
+            if os.environ.get("AGAN_DP_STUB") == "1":          # (measurement knob: the stream choreography without the collective)
                 return
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -69,6 +69,7 @@ class FlatAdam:
         Returns how many copies were needed."""
         copies = 0
         base = self.grad.data_ptr()
+        self.rebind_calls = getattr(self, "rebind_calls", 0) + 1
         it = zip(self.params, self.offsets) if indices is None else ((self.params[i], self.offsets[i]) for i in indices)
         for p, o in it:
             g = p.grad
@@ -102,6 +103,7 @@ class FlatAdam:
             elif not p._agan_grad_dst.written:
                 view.zero_()                  # no gradient reached this parameter in this backward
             p.grad = view
+        self.rebind_copies = getattr(self, "rebind_copies", 0) + copies
         return copies
 
     def join_and_rebind(self) -> None:

@@ -313,7 +313,11 @@ class GanTrainStep(ModelTrainer):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         HF.build_pack_tables()
+        # memory pools: graphs that share a pool must never run concurrently (a later capture re-uses the temporaries an earlier one
+        # freed).  The three discriminator updates replay CONCURRENTLY on their own streams, so each gets a private pool for its two
+        # graphs; the generator's graphs, which run alone, share one.
         pool = torch.cuda.graph_pool_handle()
+        d_pools = [torch.cuda.graph_pool_handle() for _ in self.Ds]
         dev = word_embs.device
         n = len(self.Ds)
         seg = SegmentedStep(self)
@@ -341,14 +345,14 @@ class GanTrainStep(ModelTrainer):
             for i in self.d_order:
                 d, opt = self.Ds[i], self.d_opts[i]
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=pool):
+                with torch.cuda.graph(gb, pool=d_pools[i]):
                     opt.zero_grad()
                     loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
                     loss.backward()
                     opt.join_and_rebind()
                     out[f"d_loss{i}"] = loss.detach()
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool):
+                with torch.cuda.graph(ga, pool=d_pools[i]):
                     opt.step(1.0 / self.d_buckets[i].world if self.d_buckets[i].active else 1.0)
                 seg.d_backward[i], seg.d_adam[i] = gb, ga
             # ---- generator update ----

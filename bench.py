@@ -330,8 +330,8 @@ def main():
     if world > 1 or os.environ.get("AGAN_DP_FORCE") == "1":        # (AGAN_DP_FORCE: one-rank rehearsal of the nccl path, dataparallel.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # every compute kernel of the step fills the chip: give the collective's stream priority, or the exchange of a bucket
-        # only starts when the backward that follows it has drained
+        # every compute kernel of the step fills the chip: give RCCL's own stream priority, or the exchange of a bucket only starts
+        # when the backward that follows it has drained (the trainer's comm streams stay at normal priority: dataparallel.py)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
