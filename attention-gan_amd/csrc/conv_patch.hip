@@ -488,7 +488,10 @@ template <int BJ> struct WgCfg {
 };
 
 // X16 / Y16: x / dy are stored in the 16-bit type of ET instead of fp32 (include/agan.h: AGAN_DT_*; one-plane modes only)
-template <int ET, int NPL, int BJ, int NT, bool X16 = false, bool Y16 = false>
+// B16 (with X16 and Y16): ROW-BLOCK staging as in conv_p16.hip -- a lane loads 16 bytes = 8 consecutive pixels of one channel, for 8
+// channels, transposes the block in registers and writes 8 [position][8 channels] items: 16 vector-memory instructions per thread
+// and tile instead of 104 (issuing those was 31 % of this kernel's time, round-2 clock64 breakdown).
+template <int ET, int NPL, int BJ, int NT, bool X16 = false, bool Y16 = false, bool B16 = false>
 __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
                                                                const Geom g, const PatchPlan pp, const int psplit, const int tiles_per_split,
                                                                const size_t slab, const float* __restrict__ x_scale,
@@ -630,6 +633,78 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __res
         }
     };
 
+    // ---- row-block staging (B16): one x item and one dy item per thread, geometry independent of the tile ----
+    // x item = (channel octet, image of the tile, patch row, 16-byte block): the blocks are aligned in the TENSOR's columns and cover
+    // the patch row's span; pixel q of a block is patch column bx_i0 + q (stride-1 convs) or, for a stride-2 phase, every second pixel
+    // (those of the phase's parity).  dy item = (cout octet, 8-pixel chunk of the tile).
+    constexpr int PXB = 8;
+    const int spanx = pp.IS * (pp.PW - 1) + 1;                       // tensor columns a patch row spans
+    const int nxb = (PXB - 1 + spanx + PXB - 1) / PXB;               // blocks that cover it whatever the alignment of its origin
+    int bx_row = 0, bx_pb = 0, bx_oct = kCH / 8, bx_xb = 0;
+    unsigned bx_lds0 = 0;
+    u32x4 xb16[8], yb16[8];
+    if (B16) {
+        const int e = tid;
+        const int t1 = e / nxb;
+        bx_xb = e - t1 * nxb;
+        const int t2 = t1 / pp.PH;
+        bx_row = t1 - t2 * pp.PH;
+        const int tb_n = 128 >> (twl + thl);
+        const int o = t2 / tb_n;
+        bx_pb = t2 - o * tb_n;
+        bx_oct = o < kCH / 8 ? o : kCH / 8;                          // (>= kCH/8: this thread has no x item)
+        bx_lds0 = (unsigned)(((bx_pb * pp.PH + bx_row) * pp.PW) * kWgPos + o * 16);
+    }
+    auto load_tile16 = [&](int mt) {
+        const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+        const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+        {   // x
+            const int x0 = pp.IS * tx0 + bx, gx0 = x0 & ~(PXB - 1);
+            const int b = tb0 + bx_pb, iy = pp.IS * (ty0 + bx_row) + by, gx = gx0 + bx_xb * PXB;
+            const int ch = c0 + bx_oct * 8;
+            const bool ok = (bx_oct < kCH / 8) & (ch < g.Cin) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)gx < (unsigned)g.IW);
+            const unsigned voff = ok ? (unsigned)(((b * g.Cin + ch) * g.IH + iy) * g.IW + gx) * 2u : kOOB;
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(x, (size_t)g.B * g.Cin * ihw * 2u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xb16[c] = buf_load_u4s(r, voff, (unsigned)(c * ihw) * 2u);
+        }
+        {   // dy: thread = (cout octet, chunk); BJ/8 octets x 16 chunks
+            const int oct = tid >> 4, pc = tid & 15;
+            const int l = pc * 8;
+            const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+            const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+            const int n = j0 + oct * 8;
+            const bool ok = (oct < BJ / 8) & (n < g.Cout) & (b < g.B) & (yq < g.OH) & (xq < g.OW);
+            const unsigned voff = ok ? (unsigned)(((b * g.Cout + n) * g.OH + yq) * g.OW + xq) * 2u : kOOB;
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * 2u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) yb16[c] = buf_load_u4s(r, voff, (unsigned)(c * ohw) * 2u);
+        }
+    };
+    auto store_tile16 = [&](int mt) {
+        const int txi = mt % pp.tiles_x;
+        const int tx0 = txi << twl;
+        const int x0 = pp.IS * tx0 + bx, gx0 = x0 & ~(PXB - 1);
+        const int i0 = gx0 + bx_xb * PXB - x0;                          // tensor-column distance of pixel 0 of the block from patch column 0
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int d = q >> 1;
+            const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
+            u32x4 vx, vy;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vx[k] = __builtin_amdgcn_perm(xb16[2 * k + 1][d], xb16[2 * k][d], sel);
+                vy[k] = __builtin_amdgcn_perm(yb16[2 * k + 1][d], yb16[2 * k][d], sel);
+            }
+            const int dcol = i0 + q;                                    // in tensor columns
+            const int col = pp.IS == 1 ? dcol : (dcol >> 1);
+            const bool okx = (bx_oct < kCH / 8) & (dcol >= 0) & (col < pp.PW) & (pp.IS == 1 || (dcol & 1) == 0);
+            if (okx) *reinterpret_cast<u32x4*>(xs + bx_lds0 + (unsigned)(col * kWgPos)) = vx;
+            if ((tid >> 4) < BJ / 8)
+                *reinterpret_cast<u32x4*>(ys + ((tid & 15) * 8 + q) * C::kYRow + (tid >> 4) * 16) = vy;
+        }
+    };
+
     // ---- transposed-read lane addresses: 16-lane group gq reads pixels 8*(gq>>1) + 4*e + q (q = (lane&15)>>2) for the 16 channels
     //      16*(gq&1) + ..., lane (lane&3) supplying columns 4*(lane&3)..+3 of row q
     const int gq = lane >> 4, li = lane & 15, rq = li >> 2, cp = li & 3;
@@ -644,8 +719,8 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __res
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (tile_beg < tile_end) {
-        load_tile(tile_beg, -1);
-        store_tile();
+        if (B16) { load_tile16(tile_beg); store_tile16(tile_beg); }
+        else { load_tile(tile_beg, -1); store_tile(); }
         __syncthreads();
         const int TW = 1 << twl;
         constexpr int nsteps = 8;                                 // 128 pixels / 16
@@ -693,7 +768,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __res
 #endif
             const bool more = mt + 1 < tile_end;
 #if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 1
-            if (more) load_tile(mt + 1, 0);
+            if (more) { if (B16) load_tile16(mt + 1); else load_tile(mt + 1, 0); }
 #endif
             AGAN_TICK(0);
             // (opaque per tile: otherwise all 8 x TPW x 2 fragment addresses of the unrolled loop are hoisted out of the tile loop and
@@ -720,7 +795,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __res
 #pragma unroll
                 for (int tg = 0; tg < NG; ++tg) {
 #if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 1
-                    if (kk == nsteps / 2 && tg == 0 && more) load_tile(mt + 1, 1);
+                    if (!B16 && kk == nsteps / 2 && tg == 0 && more) load_tile(mt + 1, 1);
 #endif
                     const int cur = (kk * NG + tg) & 1, nxt = cur ^ 1;
                     const bool last = (kk + 1 == nsteps) && (tg + 1 == NG);
@@ -752,7 +827,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(const void* __res
                 AGAN_TICK(3);
 #endif
 #if !defined(AGAN_WG_ABLATE) || AGAN_WG_ABLATE != 2
-                store_tile();
+                if (B16) store_tile16(mt + 1); else store_tile();
 #endif
                 AGAN_TICK(4);
                 __syncthreads();
@@ -1017,10 +1092,29 @@ void launch_wg_nt(const void* x, const void* dy, float* part, const Geom& g, con
         hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
 }
 // one-plane modes with typed activation storage
+// can the row-block staging take this weight gradient?  (8-pixel chunks inside tile rows, whole 16-byte blocks per tensor row, one x
+// item per thread)
+static bool wg_block16_ok(const Geom& g, const PatchPlan& pp) {
+    if (pp.twl < 3 || g.OS != 1 || (g.OW & 7) || (g.IW & 7) || (g.Cin & 7) || (g.Cout & 7)) return false;
+    const int spanx = pp.IS * (pp.PW - 1) + 1;
+    const int nxb = (7 + spanx + 7) / 8;
+    const int tb = 128 >> (pp.twl + pp.thl);
+    static const bool off = getenv("AGAN_WG_B16_OFF") != nullptr;
+    return !off && (kCH / 8) * tb * pp.PH * nxb <= 256;
+}
+template <int ET, int BJ>
+void launch_wg_b16(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st) {
+    dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
+    if (pp.NT == 9)
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, 1, BJ, 9, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, 1, BJ, 4, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
+}
 template <int ET, int BJ>
 void launch_wg_dt(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st, bool x16,
                   bool y16) {
-    if (x16 && y16) launch_wg_nt<ET, 1, BJ, true, true>(x, dy, part, g, pp, p, st);
+    if (x16 && y16 && wg_block16_ok(g, pp)) launch_wg_b16<ET, BJ>(x, dy, part, g, pp, p, st);
+    else if (x16 && y16) launch_wg_nt<ET, 1, BJ, true, true>(x, dy, part, g, pp, p, st);
     else if (x16) launch_wg_nt<ET, 1, BJ, true, false>(x, dy, part, g, pp, p, st);
     else if (y16) launch_wg_nt<ET, 1, BJ, false, true>(x, dy, part, g, pp, p, st);
     else launch_wg_nt<ET, 1, BJ>(x, dy, part, g, pp, p, st);

@@ -39,8 +39,10 @@ def _shard(rank, dev):
     return words, sent, [5, 3, 2, 4], reals, noise, eps
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bf16=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if bf16:
+        os.environ["AGAN_DP_BF16"] = "1"        # buckets travel as bf16, fp32 accumulation on arrival (dataparallel.all_reduce_bf16_)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -70,12 +72,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_mean_of_shard_gradients():
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32-exchange", "bf16-exchange"])
+def test_two_rank_step_equals_mean_of_shard_gradients(bf16):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bf16)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])

@@ -165,8 +165,10 @@ def test_grad_bucket_partition():
     assert bk.finish() == 1.0
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, bf16=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if bf16:
+        os.environ["AGAN_DP_BF16"] = "1"
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -214,6 +216,39 @@ def test_data_parallel_gradient_exchange_gloo_world2():
         opt._rebind()                      # what step() does: gradients autograd kept outside the flat buffer are copied in
         total += opt.grad
     assert torch.allclose(g0, total, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_gradient_exchange_gloo_world2():
+    """AGAN_DP_BF16=1: buckets travel as bf16 and are summed in fp32 in rank order on arrival, the sum goes back as bf16
+    (dataparallel.all_reduce_bf16_): both ranks end with  fp32(bf16(fp32(bf16(g0)) + fp32(bf16(g1))))  bit for bit -- within 2^-8 of
+    the fp32 all-reduce."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, w0, g0, nb0), (_, s1, w1, g1, nb1) = got
+    assert s0 == s1 == 0.5 and nb0 > 1 and torch.equal(w0, w1) and torch.equal(g0, g1)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
+    opt = OPT.FlatAdam(net.parameters())
+    with torch.no_grad():
+        opt.flat.copy_(w0)
+    shards = []
+    for r in range(2):
+        opt.zero_grad()
+        net(torch.randn(4, 16, generator=torch.Generator().manual_seed(r))).pow(2).sum().backward()
+        opt._rebind()
+        shards.append(opt.grad.clone())
+    want = (shards[0].to(torch.bfloat16).float() + shards[1].to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    assert torch.equal(g0, want)
+    exact = shards[0] + shards[1]
+    assert float((g0 - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
 
 
 def test_golden_fixtures_are_data_only():
