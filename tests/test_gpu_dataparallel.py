@@ -153,7 +153,10 @@ def test_two_rank_step_equals_mean_of_shard_gradients(bf16):
         scale = float(b.abs().max().clamp(min=1e-30))
         diff = (a.to(b.device) - b).abs()
         bad = int((diff > 1e-3 * scale).sum())
-        assert float(diff.max()) <= 2.05 * 2e-4 and bad <= max(2, b.numel() // 1000), f"{what}: {bad} of {b.numel()} off, max {float(diff.max()):.2e}"
+        # (Adam's first step is sign-like: a weight whose averaged gradient is within rounding of zero moves by 2 lr the other way.
+        #  The bf16 exchange rounds the gradients twice at 2^-9: a few more such weights, same 2 lr bound)
+        allowed = max(4, b.numel() // 200) if bf16 else max(2, b.numel() // 1000)
+        assert float(diff.max()) <= 2.05 * 2e-4 and bad <= allowed, f"{what}: {bad} of {b.numel()} off, max {float(diff.max()):.2e}"
 
     for k, v in G.state_dict().items():
         if k.endswith((".weight", ".bias")):
