@@ -292,6 +292,7 @@ struct P16Plan {
     int bn, ntiles, ncls, ksplit, stages_per_split;
     int buf_bytes;                      // one LDS patch buffer (the kernel holds two)
     int lds_epi;                        // 16-bit output leaves through LDS as 16-byte stores
+    int px2;                            // GK 1 on a stride-2 lattice: both column-parity classes in one workgroup (grid classes = row parities)
     size_t slab, ws_bytes;
     FastDiv dNXB, dPH, dTB;
 };

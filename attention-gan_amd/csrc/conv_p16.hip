@@ -62,7 +62,11 @@ template <> struct GKTraits<2> { static constexpr int R = 4, S = 4, IS = 2, CHS 
 
 // ET: 0 bf16 / 1 f16 (MFMA operand type = 16-bit storage type).  IN16 / OUT16: the gathered / produced tensor is stored in that
 // 16-bit type (else fp32).  NI: staging items per thread and stage.
-template <int ET, int GK, int BN, bool IN16, bool OUT16, int NI>
+// PX2 (GK 1 on a stride-2 output lattice -- the data gradient of conv4x4-s2, the folded upsample conv): one workgroup computes BOTH
+// column-parity classes of 64 lattice points from ONE staged patch.  Its accumulator fragments come in pairs (class px = 0, 1 of the
+// same 32 lattice points), so a lane holds two ADJACENT output pixels and the epilogue writes whole contiguous rows -- as separate
+// class launches every store touched every second pixel (2-byte stores at a 4-byte stride) and the patch was staged twice.
+template <int ET, int GK, int BN, bool IN16, bool OUT16, int NI, bool PX2 = false>
 __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict__ in, const unsigned short* __restrict__ wk,
                                                           const float* __restrict__ bias, void* __restrict__ out, const Geom g,
                                                           const P16Plan pp, const int act, const void* __restrict__ lrelu_mask) {
@@ -81,8 +85,11 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
 #ifndef AGAN_P16_WD_FULL
 #define AGAN_P16_WD_FULL 0
 #endif
-    constexpr int WD = (AGAN_P16_WD_FULL && NI == 1) ? SPS : (SPS == 18 ? 9 : 8);
+    constexpr int WD = PX2 ? 4 : ((AGAN_P16_WD_FULL && NI == 1) ? SPS : (SPS == 18 ? 9 : 8));     // (PX2: two fragments per slot)
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
+    static_assert(!PX2 || (GK == 1 && TM >= 2), "PX2: 2x2-tap classes, at least two pixel fragments per wave");
+    constexpr int NPX = PX2 ? 2 : 1;                 // column-parity classes per workgroup
+    constexpr int LP = PX2 ? 6 : 7;                  // log2 of the lattice points per workgroup tile
     constexpr int NWR = NI * PXB;                    // LDS item writes per thread and stage
     constexpr int U0 = SPS / 2;                      // first k-step that carries item writes: the loads get SPS/2 k-steps to land
     constexpr int WPS = (NWR + (SPS - U0) - 1) / (SPS - U0);
@@ -102,25 +109,27 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
         cls = F % ncls;  F /= ncls;
         mt = F % mtiles; split = F / mtiles;
     }
-    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int py = PX2 ? cls : cls / g.OS, px = PX2 ? 0 : cls - py * g.OS;       // (PX2: the grid's classes are the ROW parities)
     const int n0 = nt * BN;
     const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
     const int twl = pp.twl, thl = pp.thl;
-    const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
+    const int tb0 = tbi << (LP - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
     const int ihw = g.IH * g.IW;
     const int stage_beg = split * pp.stages_per_split, stage_end = min(pp.nstages, stage_beg + pp.stages_per_split);
 
     // patch origin in the gathered tensor (row / column of LDS row 0 / of the first needed column), and the aligned column the
     // 16-byte blocks start at
     const int dmin = (IS == 1 && g.DY < 0) ? -(R - 1) : 0;
-    const int y0 = IS * ty0 + dmin + (py ? g.OY1 : g.OY0), x0 = IS * tx0 + dmin + (px ? g.OY1 : g.OY0);
+    // (PX2: the patch starts at the left class's first column -- OY0 <= OY1 -- and is OY1 - OY0 columns wider)
+    const int y0 = IS * ty0 + dmin + (py ? g.OY1 : g.OY0), x0 = IS * tx0 + dmin + ((px && !PX2) ? g.OY1 : g.OY0);
     const int gx0 = x0 & ~(PXB - 1);
     const int dx0 = x0 - gx0;
     const int LW = pp.LW, LWH = LW >> 1;
 
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * ESZ);
     const size_t wbytes_cls = (size_t)pp.wsteps * g.Nld * 32;
-    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)cls * wbytes_cls, wbytes_cls);
+    const int wcls = PX2 ? py * 2 : cls;              // packed-weight class (row parity x 2 + column parity); PX2 reads wcls and wcls + 1
+    const __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const unsigned char*>(wk) + (size_t)wcls * wbytes_cls, NPX * wbytes_cls);
 
     // ---- staging items: (channel octet o, image pb, patch row j, 16-byte block xb), xb fastest (lanes walk along a row) ----
     unsigned it_voff[NI], it_lds[NI];
@@ -169,12 +178,14 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
     };
 
     // ---- MFMA operand addressing ----
+    // fragment t of a wave: lattice points lat(t) * 32 + l31 (PX2: fragments 2f, 2f + 1 = classes px 0, 1 of lattice fragment f)
+    auto lat_of = [&](int t) { return PX2 ? (wm * TM + t) >> 1 : wm * TM + t; };
     unsigned lbase[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        const int l = (wm * TM + t) * 32 + l31;
+        const int l = lat_of(t) * 32 + l31;
         const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-        lbase[t] = (unsigned)(((tb * pp.PH + IS * ty) * LW + tx + (IS == 1 ? dx0 : 0)) * PB + lh * 16);
+        lbase[t] = (unsigned)(((tb * pp.PH + IS * ty) * LW + tx + (IS == 1 ? dx0 : 0) + ((PX2 && (t & 1)) ? g.OY1 - g.OY0 : 0)) * PB + lh * 16);
     }
     unsigned tapoff[NT];
 #pragma unroll
@@ -201,8 +212,11 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
     };
     const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
     const unsigned wstep = (unsigned)(g.Nld * 32);
-    u32x4 wf[WD];
-    auto load_w = [&](int slot, int q) { wf[slot] = ld16(rwk, wlane, (unsigned)min(q, pp.wsteps - 1) * wstep); };
+    u32x4 wf[WD][NPX];
+    auto load_w = [&](int slot, int q) {
+#pragma unroll
+        for (int c = 0; c < NPX; ++c) wf[slot][c] = ld16(rwk, wlane + (unsigned)(c * wbytes_cls), (unsigned)min(q, pp.wsteps - 1) * wstep);
+    };
 
     f32x16 acc[TM];
 #pragma unroll
@@ -227,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
             for (int m = 0; m < TM; ++m) af[0][m] = *reinterpret_cast<const u32x4*>(cur + lbase[m] + tapoff[tap_of(0)] + choff_of(0));
 #pragma unroll
             for (int u = 0; u < SPS; ++u) {
-                const u32x4 w = wf[u % WD];
+                u32x4 w[NPX];
+#pragma unroll
+                for (int c = 0; c < NPX; ++c) w[c] = wf[u % WD][c];
                 {   // weights WD k-steps ahead (possibly in the next stage; past the last stage: a harmless repeat)
                     const int u2 = u + WD;
                     if (u2 < SPS) load_w(u % WD, wq_of(stage, u2));
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
                         af[(u + 1) & 1][m] = *reinterpret_cast<const u32x4*>(cur + lbase[m] + tapoff[tap_of(u + 1)] + choff_of(u + 1));
                 }
 #pragma unroll
-                for (int m = 0; m < TM; ++m) acc[m] = mfma16<ET>(w, af[u & 1][m], acc[m]);
+                for (int m = 0; m < TM; ++m) acc[m] = mfma16<ET>(w[PX2 ? (m & 1) : 0], af[u & 1][m], acc[m]);
                 __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);      // next step's LDS reads first ...
                 __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);      // ... then this step's MFMAs
                 if (u >= U0 && more) {
@@ -298,6 +314,52 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
         }
         return;
     }
+    if (PX2) {
+        // fragments 2f / 2f + 1 hold output columns 2 xq / 2 xq + 1 of the same lattice point: one 4-byte (16-bit) or 8-byte (fp32)
+        // store per lane and channel, 32 lanes = one contiguous 128 / 256-byte piece of an output row
+#pragma unroll
+        for (int t = 0; t < TM; t += 2) {
+            const int l = lat_of(t) * 32 + l31;
+            const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+            const int b = tb0 + tb, yq = ty0 + ty, xq = tx0 + tx;
+            const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+            const unsigned pix = (unsigned)(b * g.Cout + nw + 4 * lh) * (unsigned)ohw + (unsigned)((yq * 2 + py) * g.OW + xq * 2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nr = (r & 3) + 8 * (r >> 2);
+                float v0 = acc[t][r], v1 = acc[t + 1][r];
+                const bool ok = pvalid & (nfull || (nw + nr + 4 * lh < g.Cout));
+                if (split_out) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, f32x2{v0, v1}), rslab,
+                                                          ok ? pix * 4u : kOOB, (unsigned)nr * (unsigned)ohw * 4u, 0);
+                    continue;
+                }
+                if (add_bias) {
+                    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)(nw + 4 * lh) * 4u, (unsigned)nr * 4u, 0));
+                    v0 += bv; v1 += bv;
+                }
+                if (lrelu) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
+                if (OUT16) {
+                    const unsigned vo = ok ? pix * 2u : kOOB, so = (unsigned)nr * (unsigned)ohw * 2u;
+                    if (masked) {
+                        const unsigned m2 = __builtin_amdgcn_raw_buffer_load_b32(rmask, vo, so, 0);
+                        v0 = up16<ET>((unsigned short)(m2 & 0xFFFFu)) > 0.f ? v0 : 0.2f * v0;
+                        v1 = up16<ET>((unsigned short)(m2 >> 16)) > 0.f ? v1 : 0.2f * v1;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(pack2<ET>(v0, v1), rout, vo, so, 0);
+                } else {
+                    const unsigned vo = ok ? pix * 4u : kOOB, so = (unsigned)nr * (unsigned)ohw * 4u;
+                    if (masked) {
+                        const f32x2 m2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rmask, vo, so, 0));
+                        v0 = m2[0] > 0.f ? v0 : 0.2f * v0;
+                        v1 = m2[1] > 0.f ? v1 : 0.2f * v1;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, f32x2{v0, v1}), rout, vo, so, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int l = (wm * TM + t) * 32 + l31;
@@ -346,9 +408,30 @@ void launch_ni(const void* in, const void* wk, const float* bias, void* dst, con
     else AGAN_P16_LAUNCH(2);
 #undef AGAN_P16_LAUNCH
 }
+// both column-parity classes in one workgroup (GK 1 on a stride-2 lattice, 64- or 128-channel tiles, one staging item per thread)
+template <int ET, int BN, bool IN16, bool OUT16>
+void launch_px2(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
+                hipStream_t st) {
+    dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
+    const unsigned short* w = static_cast<const unsigned short*>(wk);
+    const size_t smem = (size_t)2 * p.buf_bytes;
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr_;
+    hipLaunchKernelGGL((conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask);
+}
 template <int ET, int GK, int BN>
 void launch_dt(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,
                hipStream_t st, bool in16, bool out16) {
+    if constexpr (GK == 1 && BN >= 64) {
+        if (p.px2) {
+            if (in16 && out16) launch_px2<ET, BN, true, true>(in, wk, bias, dst, g, p, act, mask, st);
+            else if (in16) launch_px2<ET, BN, true, false>(in, wk, bias, dst, g, p, act, mask, st);
+            else if (out16) launch_px2<ET, BN, false, true>(in, wk, bias, dst, g, p, act, mask, st);
+            else launch_px2<ET, BN, false, false>(in, wk, bias, dst, g, p, act, mask, st);
+            return;
+        }
+    }
     if (in16 && out16) launch_ni<ET, GK, BN, true, true>(in, wk, bias, dst, g, p, act, mask, st);
     else if (in16) launch_ni<ET, GK, BN, true, false>(in, wk, bias, dst, g, p, act, mask, st);
     else if (out16) launch_ni<ET, GK, BN, false, true>(in, wk, bias, dst, g, p, act, mask, st);
@@ -382,7 +465,7 @@ namespace conv {
 
 // Plan of the row-block gather for geometry g with the gathered tensor stored as fp32 (in16 = false) or in 16 bits.  p.ok == 0:
 // this kernel does not take the call (the caller falls back to conv_patch.hip's kernel on fp32 tensors).
-P16Plan plan_p16(const Geom& g, bool in16) {
+static P16Plan plan_impl(const Geom& g, bool in16, bool allow_px2) {
     P16Plan p;
     memset(&p, 0, sizeof(p));
     if (g.Cout <= 4 || g.Cin <= 4 || (g.Cin & 7)) return p;
@@ -393,31 +476,36 @@ P16Plan plan_p16(const Geom& g, bool in16) {
     else return p;
     p.PXB = in16 ? 8 : 4;
     if (g.IW % p.PXB) return p;                       // rows of the gathered tensor must be whole 16-byte blocks
+    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
+    // both column-parity classes of a stride-2 lattice in one workgroup (64 lattice points x 2): see the kernel's PX2
+    static const bool px2_off = getenv("AGAN_P16_PX2_OFF") != nullptr;
+    p.px2 = (allow_px2 && p.gk == 1 && g.OS == 2 && p.bn >= 64 && g.OY1 >= g.OY0 && !px2_off) ? 1 : 0;
+    const int lp = p.px2 ? 6 : 7;
     p.twl = std::min(5, pow2ceil_log_(g.OWs));
-    p.thl = std::min(7 - p.twl, pow2ceil_log_(g.OHs));
+    p.thl = std::min(lp - p.twl, pow2ceil_log_(g.OHs));
     const int TW = 1 << p.twl, TH = 1 << p.thl;
-    p.TB = 128 >> (p.twl + p.thl);
+    p.TB = (1 << lp) >> (p.twl + p.thl);
     p.tiles_x = cdiv(g.OWs, TW);
     p.tiles_y = cdiv(g.OHs, TH);
     p.tiles_b = cdiv(g.B, p.TB);
     p.mtiles = p.tiles_x * p.tiles_y * p.tiles_b;
     p.PH = IS * (TH - 1) + R;
-    const int PW = IS * (TW - 1) + R;
+    const int PW = IS * (TW - 1) + R + (p.px2 ? g.OY1 - g.OY0 : 0);
     p.NXB = cdiv(p.PXB - 1 + PW, p.PXB);              // blocks that cover the patch columns whatever the alignment of its origin
     p.LW = p.NXB * p.PXB;
     p.CHS = CHS;
     p.nitems = (CHS / 8) * p.TB * p.PH * p.NXB;
     p.NI = cdiv(p.nitems, 256);
     if (p.NI > 2) return p;
+    if (p.px2 && p.NI > 1) return plan_impl(g, in16, false);
     p.buf_bytes = p.TB * p.PH * p.LW * (CHS * 2 + 16);
     // (two workgroups per CU up to 78 KB; the 8x8 / 16x16 layers, whose tiles span several images, take up to 150 KB and run one)
     if (2 * p.buf_bytes > 150 * 1024) return p;
     p.nstages = cdiv(g.Cin, CHS);
     // k-steps of the packed weights (conv_patch.hip layout: 32-channel chunks x phases x taps x 2)
     p.wsteps = cdiv(g.Cin, 32) * (IS == 2 ? 4 : 1) * (IS == 2 ? 4 : R * R) * 2;
-    p.bn = g.Cout >= 96 ? 128 : (g.Cout >= 48 ? 64 : 32);
     p.ntiles = cdiv(g.Cout, p.bn);
-    p.ncls = g.OS * g.OS;
+    p.ncls = p.px2 ? 2 : g.OS * g.OS;
     const int tiles = p.mtiles * p.ntiles * p.ncls;
     int ks = 1;
     if (tiles < 512) ks = std::max(1, std::min({512 / tiles, p.nstages / 4, 32}));
@@ -433,6 +521,8 @@ P16Plan plan_p16(const Geom& g, bool in16) {
     p.ok = 1;
     return p;
 }
+
+P16Plan plan_p16(const Geom& g, bool in16) { return plan_impl(g, in16, true); }
 
 void launch_p16_gather(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int prec, int act,
                        const void* lrelu_mask, hipStream_t st, bool in16, bool out16) {
