@@ -318,6 +318,10 @@ class GanTrainStep(ModelTrainer):
         # graphs; the generator's graphs, which run alone, share one.
         pool = torch.cuda.graph_pool_handle()
         d_pools = [torch.cuda.graph_pool_handle() for _ in self.Ds]
+        # thread-local capture: the process group's watchdog thread polls its events (hipEventQuery) at any time, which a GLOBAL-mode
+        # capture turns into "operation not permitted when stream is capturing" in THAT thread and kills the process (seen once in
+        # the one-rank nccl rehearsal, round 3)
+        mode = "thread_local"
         dev = word_embs.device
         n = len(self.Ds)
         seg = SegmentedStep(self)
@@ -332,7 +336,7 @@ class GanTrainStep(ModelTrainer):
             g0 = torch.cuda.CUDAGraph()
             if self.rng.device.type == "cuda":
                 g0.register_generator_state(self.rng)
-            with torch.cuda.graph(g0, pool=pool):
+            with torch.cuda.graph(g0, pool=pool, capture_error_mode=mode):
                 HF.amax_begin_step(dev)
                 labels = self._make_match_labels(b)
                 mask = self._make_mask(lengths, word_embs.shape[2])
@@ -345,19 +349,19 @@ class GanTrainStep(ModelTrainer):
             for i in self.d_order:
                 d, opt = self.Ds[i], self.d_opts[i]
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=d_pools[i]):
+                with torch.cuda.graph(gb, pool=d_pools[i], capture_error_mode=mode):
                     opt.zero_grad()
                     loss = self.disc_loss.get_loss(d, fakes[i].detach(), real_imgs[i])
                     loss.backward()
                     opt.join_and_rebind()
                     out[f"d_loss{i}"] = loss.detach()
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=d_pools[i]):
+                with torch.cuda.graph(ga, pool=d_pools[i], capture_error_mode=mode):
                     opt.step(1.0 / self.d_buckets[i].world if self.d_buckets[i].active else 1.0)
                 seg.d_backward[i], seg.d_adam[i] = gb, ga
             # ---- generator update ----
             gg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gg, pool=pool):
+            with torch.cuda.graph(gg, pool=pool, capture_error_mode=mode):
                 self.g_opt.zero_grad()
                 for d in self.Ds:
                     d.requires_grad_(False)
@@ -383,7 +387,7 @@ class GanTrainStep(ModelTrainer):
                     d.requires_grad_(True)
                 self.g_opt.join_and_rebind()
             gadam = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gadam, pool=pool):
+            with torch.cuda.graph(gadam, pool=pool, capture_error_mode=mode):
                 self.g_opt.step(1.0 / self.g_buckets.world if self.g_buckets.active else 1.0)
             seg.g_backward, seg.g_adam = gg, gadam
             out["fake_imgs"] = [f.detach() for f in fakes]
