@@ -107,7 +107,8 @@ class GanTrainStep(ModelTrainer):
 
     def __init__(self, generator: Module, discriminators: Sequence[Module], image_encoder: Optional[Callable] = None,
                  gen_lr: float = 2e-4, disc_lr: float = 2e-4, gamma1: float = 4.0, gamma2: float = 5.0, gamma3: float = 10.0,
-                 wlambda: float = 5.0, slambda: float = 5.0, bucket_bytes: int = 64 << 20, group=None, seed: int = 0):
+                 wlambda: float = 5.0, slambda: float = 5.0, bucket_bytes: int = 64 << 20, group=None, seed: int = 0,
+                 g_bucket_bytes: Optional[int] = None):
         super().__init__()
         self.G, self.Ds, self.image_encoder = generator, list(discriminators), image_encoder
         self.group = group
@@ -125,7 +126,9 @@ class GanTrainStep(ModelTrainer):
         self.sample_rng.manual_seed(int(seed) * 1000003 + 500009 + self.rank)
         self.g_opt = FlatAdam(self.G.parameters(), lr=gen_lr, betas=(0.5, 0.999))
         self.d_opts = [FlatAdam(d.parameters(), lr=disc_lr, betas=(0.5, 0.999)) for d in self.Ds]
-        self.g_buckets = GradBuckets(self.g_opt, bucket_bytes, group)
+        # the generator's 28 MB would be ONE 64 MB bucket, launched when its whole backward is done and fully exposed: it goes out in
+        # 8 MB buckets instead, so all but the last travel under the ~10 ms of backward that remain
+        self.g_buckets = GradBuckets(self.g_opt, min(bucket_bytes, 8 << 20) if g_bucket_bytes is None else g_bucket_bytes, group)
         self.d_buckets = [GradBuckets(o, bucket_bytes, group) for o in self.d_opts]
         # issue order of the three independent discriminator updates: LARGEST first (Disc256: 273 MB of gradients, the long pole of
         # the exchange), so that its buckets travel while the smaller discriminators still compute.  Results do not depend on it.

@@ -134,11 +134,12 @@ def baseline_metric_name():
         return "train images/sec at 256x256 stage-3, batch 24/GPU"
 
 
-def measured_traffic(kernel, mode):
-    """HBM bytes per launch from the COMMITTED PMC passes, not from this run (profiles/r02_<mode>_traffic.json, made by
+def measured_traffic(kernel, mode, storage="f32"):
+    """HBM bytes per launch from the COMMITTED PMC passes, not from this run (profiles/r03_<mode>[_s16]_traffic.json, made by
     profiles/make_counters.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command; gfx950 x2 read correction);
     None if that kernel was not measured."""
-    for name in (f"r02_{mode}_traffic.json", "r01_traffic.json"):
+    s16 = "_s16" if storage != "f32" else ""
+    for name in (f"r03_{mode}{s16}_traffic.json", f"r02_{mode}_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)["kernels"].get(kernel, {}).get("traffic")
@@ -452,7 +453,7 @@ def main():
             achieved = falg / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": measured_traffic(name, args.precision),
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": measured_traffic(name, args.precision, args.storage),
                         "traffic_source": "profiles/ (committed rocprofv3 PMC passes of this command), not this run",
                         "algorithmic_bytes_per_launch": round(nbytes / n),
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "timing": roofline_timing, "executed_tflops": round(fexec / (ms * 1e-3) / 1e12, 2),

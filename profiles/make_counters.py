@@ -76,6 +76,9 @@ def bench_name(kernel, mode):
         for n in (128, 64, 32):
             if f", {n}, 4>" in kernel or f", {n}, 9>" in kernel:
                 return f"conv_gather_{mode}_n{n}"
+    if "conv_p16_kernel<" in kernel:          # <ET, GK, BN, IN16, OUT16, NI[, PX2]>: the cout tile is the 3rd template argument
+        args = kernel.split("conv_p16_kernel<")[1].split(">")[0].split(",")
+        return f"conv_gather_{mode}_n{int(args[2])}"
     return None
 
 
@@ -94,7 +97,8 @@ def read_pass(directory):
 
 def main():
     prefix, out_dir, tag = sys.argv[1:4]
-    mode = tag.split("_")[-1]
+    parts = tag.split("_")                       # r03_bf16 / r03_bf16_s16 (16-bit activation storage)
+    mode = parts[-2] if parts[-1] == "s16" else parts[-1]
     mfma, fetch, write = read_pass(prefix + "_mfma"), read_pass(prefix + "_fetch"), read_pass(prefix + "_write")
     stats = glob.glob(os.path.join(prefix + "_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
@@ -139,7 +143,8 @@ def main():
                    "write_size": round(c["write"] / max(1, c["nw"])),
                    "traffic": round(2 * c["fetch"] / max(1, c["nf"]) + c["write"] / max(1, c["nw"]))} for b, c in sorted(conv.items())}
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over `python bench.py --steps 2 "
-                     f"--warmup 1 --no-cpu-baseline --no-variants --graph off --precision {mode}`; summarised by profiles/make_counters.py",
+                     f"--warmup 1 --no-cpu-baseline --no-variants --graph off --precision {mode}" + (f" --storage {mode}" if parts[-1] == "s16" else "") +
+                     "`; summarised by profiles/make_counters.py",
            "unit": "bytes per launch (average over all launches of the kernel in the run)",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH_SIZE + WRITE_SIZE; "
                          "the x2 is calibrated for 16-B/lane streams, so it is an upper bound for the 4-B/lane patch loads",
