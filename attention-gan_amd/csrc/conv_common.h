@@ -286,11 +286,11 @@ struct P16Plan {
     int gk;                             // 0: 3x3 s1, 1: 2x2 s1 (parity classes), 2: 4x4 s2
     int twl, thl, TB;                   // tile = TB images x 2^thl rows x 2^twl columns of the output lattice (128 points)
     int tiles_x, tiles_y, tiles_b, mtiles;
-    int PH, LW, NXB, PXB, CHS;          // patch rows per image, LDS row width (positions), 16-byte blocks per row, pixels per block, channels per stage
+    int PH, PW, LW, NXB, PXB, CHS;      // patch rows / columns per image, LDS row width (positions), 16-byte blocks per row, pixels per block, channels per stage
     int nitems, NI;                     // staging items per stage / per thread
     int nstages, wsteps;                // stages (CHS-channel chunks); k-steps of the packed weights per class
     int bn, ntiles, ncls, ksplit, stages_per_split;
-    int buf_bytes;                      // one LDS patch buffer (the kernel holds two)
+    int buf_bytes, smem_bytes;          // one LDS patch buffer (the kernel holds two); dynamic LDS of the launch
     int lds_epi;                        // 16-bit output leaves through LDS as 16-byte stores
     int px2;                            // GK 1 on a stride-2 lattice: both column-parity classes in one workgroup (grid classes = row parities)
     size_t slab, ws_bytes;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
 
     // ---- staging items: (channel octet o, image pb, patch row j, 16-byte block xb), xb fastest (lanes walk along a row) ----
     unsigned it_voff[NI], it_lds[NI];
-    int it_oct[NI];
+    int it_oct[NI], it_x0[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e = tid + i * 256;
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
         it_oct[i] = (e < pp.nitems) ? o : CHS;          // (>= CHS/8: no channel of any stage)
         it_voff[i] = ok ? (unsigned)(((b * g.Cin + o * 8) * g.IH + iy) * g.IW + gx) * (unsigned)ESZ : kOOB;
         const int row = pb * pp.PH + j;
-        it_lds[i] = (unsigned)((row * LW + (IS == 1 ? xb * PXB : xb * (PXB / 2))) * PB + o * 16);
+        it_lds[i] = (unsigned)(row * LW * PB + o * 16);  // the item's LDS row
+        it_x0[i] = xb * PXB - dx0;                       // patch column of the block's first pixel (the blocks are aligned in the TENSOR)
     }
-    const unsigned oddoff = (unsigned)(LWH * PB);        // IS == 2: odd columns live in the second half of an LDS row
     u32x4 blk[NI][8];
     auto load_items = [&](int chunk) {
         const int c0 = chunk * CHS;
@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
             for (int k = 0; k < 4; ++k)
                 v[k] = pack2<ET>(__uint_as_float(blk[i][2 * k][q]), __uint_as_float(blk[i][2 * k + 1][q]));
         }
-        const unsigned a = IS == 1 ? it_lds[i] + (unsigned)(q * PB) : it_lds[i] + ((q & 1) ? oddoff : 0u) + (unsigned)((q >> 1) * PB);
-        if (it_oct[i] < CHS / 8) *reinterpret_cast<u32x4*>(dstbuf + a) = v;
+        // LDS rows hold exactly the patch's columns (IS == 2: [even | odd]); pixels of the aligned blocks that fall outside are dropped
+        const int xl = it_x0[i] + q;
+        const unsigned a = it_lds[i] + (unsigned)((IS == 1 ? xl : (xl & 1) * LWH + (xl >> 1)) * PB);
+        if ((it_oct[i] < CHS / 8) & ((unsigned)xl < (unsigned)pp.PW)) *reinterpret_cast<u32x4*>(dstbuf + a) = v;
     };
 
     // ---- MFMA operand addressing ----
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
     for (int t = 0; t < TM; ++t) {
         const int l = lat_of(t) * 32 + l31;
         const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-        lbase[t] = (unsigned)(((tb * pp.PH + IS * ty) * LW + tx + (IS == 1 ? dx0 : 0) + ((PX2 && (t & 1)) ? g.OY1 - g.OY0 : 0)) * PB + lh * 16);
+        lbase[t] = (unsigned)(((tb * pp.PH + IS * ty) * LW + tx + ((PX2 && (t & 1)) ? g.OY1 - g.OY0 : 0)) * PB + lh * 16);
     }
     unsigned tapoff[NT];
 #pragma unroll
@@ -195,8 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
             const int ro = r * g.DY - dmin, so = s * g.DY - dmin;
             tapoff[t] = (unsigned)((ro * LW + so) * PB);
         } else {
-            const int xs = s + dx0;
-            tapoff[t] = (unsigned)((r * LW + (xs & 1) * LWH + (xs >> 1)) * PB);
+            tapoff[t] = (unsigned)((r * LW + (s & 1) * LWH + (s >> 1)) * PB);
         }
     }
     // k-step u of a stage -> (tap, byte offset of its 16 channels inside a position, k-step of the packed weights)
@@ -396,7 +397,7 @@ void launch_ni(const void* in, const void* wk, const float* bias, void* dst, con
                hipStream_t st) {
     dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
-    const size_t smem = (size_t)2 * p.buf_bytes;
+    const size_t smem = (size_t)p.smem_bytes;
 #define AGAN_P16_LAUNCH(NI_)                                                                                                             \
     do {                                                                                                                                 \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), \
@@ -414,7 +415,7 @@ void launch_px2(const void* in, const void* wk, const float* bias, void* dst, co
                 hipStream_t st) {
     dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
-    const size_t smem = (size_t)2 * p.buf_bytes;
+    const size_t smem = (size_t)p.smem_bytes;
     static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr_;
@@ -491,8 +492,9 @@ static P16Plan plan_impl(const Geom& g, bool in16, bool allow_px2) {
     p.mtiles = p.tiles_x * p.tiles_y * p.tiles_b;
     p.PH = IS * (TH - 1) + R;
     const int PW = IS * (TW - 1) + R + (p.px2 ? g.OY1 - g.OY0 : 0);
-    p.NXB = cdiv(p.PXB - 1 + PW, p.PXB);              // blocks that cover the patch columns whatever the alignment of its origin
-    p.LW = p.NXB * p.PXB;
+    p.NXB = cdiv(p.PXB - 1 + PW, p.PXB);              // 16-byte blocks that cover the patch columns whatever the alignment of its origin
+    p.PW = PW;
+    p.LW = (PW + 1) & ~1;                             // LDS rows hold the patch's own columns (an even count: stride-2 rows are [even | odd])
     p.CHS = CHS;
     p.nitems = (CHS / 8) * p.TB * p.PH * p.NXB;
     p.NI = cdiv(p.nitems, 256);
@@ -514,7 +516,8 @@ static P16Plan plan_impl(const Geom& g, bool in16, bool allow_px2) {
     p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
     p.ws_bytes = p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0;
     // LDS-staged 16-byte output stores (16-bit output only): unit-stride lattice, rows of whole 8-pixel chunks, room for [bn][136] x 2 B
-    p.lds_epi = (g.OS == 1 && p.twl >= 3 && (g.OW & 7) == 0 && 2 * p.buf_bytes >= p.bn * 272) ? 1 : 0;
+    p.lds_epi = (g.OS == 1 && p.twl >= 3 && (g.OW & 7) == 0) ? 1 : 0;
+    p.smem_bytes = std::max(2 * p.buf_bytes, p.lds_epi ? p.bn * 272 : 0);
     p.dNXB = make_fastdiv((unsigned)p.NXB);
     p.dPH = make_fastdiv((unsigned)p.PH);
     p.dTB = make_fastdiv((unsigned)p.TB);

@@ -62,6 +62,8 @@ CASES = [
     ("down", 2, 24, 32, 48, 48, 4, True),        # non-square, channel count not a multiple of the 16 / 64-channel stages
     ("up", 2, 64, 16, 16, 64, 3, True),          # folded upsample conv: GK 1 forward (four classes), GK 2 data gradient
     ("up", 2, 16, 8, 8, 16, 3, True),
+    ("down", 6, 256, 8, 8, 128, 4, True),        # 4x4 outputs: tiles of 8 images, K split
+    ("same", 10, 128, 8, 8, 64, 3, True),        # 8x8 images, tiles of 2 images, ragged last tile
     ("same", 2, 64, 4, 4, 96, 3, True),          # rows shorter than a 16-byte block: falls back through fp32
 ]
 
