@@ -801,7 +801,11 @@ def glu(x: Tensor) -> Tensor:
 class _AttentionFn(Function):
     @staticmethod
     def forward(ctx, images, words, weight, mask, scale, wdst):
-        images, words = _dev(images, "attention images"), _dev(words, "attention words")
+        # images / context / their gradients keep the activation storage in force (typed kernels: agan_attn_*_dt); words, the
+        # projection and the attention map stay fp32
+        images, words = _act(images, "attention images"), _dev(words, "attention words")
+        if images.dtype != torch.float32 and _dt(images) != get_activation_storage():
+            images = images.float()
         w = _dev(weight.detach(), "attention conv1 weight")
         B, C, H, W = images.shape
         Bw, E, T = words.shape
@@ -811,8 +815,8 @@ class _AttentionFn(Function):
         proj = torch.empty((B, C, T), dtype=torch.float32, device=images.device)
         ctxt = torch.empty_like(images)
         attn = torch.empty((B, T, H, W), dtype=torch.float32, device=images.device)
-        L.call("agan_attn_fwd", _p(images), _p(words), _p(w), _p(m), float(scale), _p(proj), _p(ctxt), _p(attn),
-               B, C, E, T, H * W, _stream())
+        L.call("agan_attn_fwd_dt", _p(images), _p(words), _p(w), _p(m), float(scale), _p(proj), _p(ctxt), _p(attn),
+               B, C, E, T, H * W, _stream(), _dt(images))
         ctx.save_for_backward(images, words, w, proj, attn)
         ctx.scale, ctx.wdst = float(scale), wdst
         ctx.set_materialize_grads(False)     # the attention map usually feeds nothing: no zero-filled 16 MB gradient for it
@@ -824,7 +828,10 @@ class _AttentionFn(Function):
         images, words, w, proj, attn = ctx.saved_tensors
         B, C, H, W = images.shape
         _, E, T = words.shape
-        dctx = _dev(dctx, "attention dctx") if dctx is not None else None
+        if dctx is not None:
+            dctx = _act(dctx, "attention dctx")
+            if dctx.dtype != images.dtype:
+                dctx = dctx.to(images.dtype)
         dattn = _dev(dattn, "attention dattn") if dattn is not None else None
         dimages, dwords = torch.empty_like(images), torch.empty_like(words)
         # a frozen projection (requires_grad False) still needs d(proj) for nothing: its gradient goes to scratch, not into the
@@ -834,8 +841,8 @@ class _AttentionFn(Function):
             dw = None
         nbytes = L.load().agan_attn_bwd_ws_bytes(B, C, T, H * W)
         ws, wsp = _ws(nbytes, images)
-        L.call("agan_attn_bwd", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
-               _p(dimages), _p(dwords), _p(dwbuf), B, C, E, T, H * W, wacc, wsp, nbytes, _stream())
+        L.call("agan_attn_bwd_dt", _p(images), _p(words), _p(w), _p(proj), _p(attn), _p(dctx), _p(dattn), ctx.scale,
+               _p(dimages), _p(dwords), _p(dwbuf), B, C, E, T, H * W, wacc, wsp, nbytes, _stream(), _dt(images))
         return dimages, dwords, dw, None, None, None
 
 

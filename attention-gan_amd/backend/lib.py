@@ -80,6 +80,8 @@ _SIGNATURES = {
     "agan_attn_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_attn_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "agan_attn_bwd": (c_int, [_P] * 7 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "agan_attn_fwd_dt": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int]),
+    "agan_attn_bwd_dt": (c_int, [_P] * 7 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, c_int]),
     "agan_func_attention_fwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_func_attention_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "agan_words_loss_save_elems": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256) void attn_proj_kernel(const float* __restrict_
     if ((lane & (64 / TMAX - 1)) == 0 && t_own < T) proj[(size_t)bc * T + t_own] = r;
 }
 
-template <int TMAX>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ images, const float* __restrict__ proj,
-                                                       const int64_t* __restrict__ mask, float scale, float* __restrict__ ctx,
+// DT: storage type of `images` and `ctx` (include/agan.h: AGAN_DT_*); the attention map, projections and all arithmetic stay fp32
+template <int TMAX, int DT = AGAN_DT_F32>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ images, const float* __restrict__ proj,
+                                                       const int64_t* __restrict__ mask, float scale, void* __restrict__ ctx,
                                                        float* __restrict__ attn, int C, int T, int HW) {
     __shared__ float pj[kMaxC][TMAX];
     __shared__ float neg[TMAX];   // 0 for a live word, -inf for masked / padded
@@ -69,12 +70,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     __syncthreads();
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
-    const float* img = images + (size_t)b * C * HW + p;
+    const size_t img0 = (size_t)b * C * HW + p;
     float sc[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) sc[t] = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float v = img[(size_t)c * HW];
+        const float v = ld1<DT>(images, img0 + (size_t)c * HW);
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) sc[t] += v * pj[c][t];
     }
@@ -97,22 +98,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         sc[t] *= inv;
         if (t < T) ao[(size_t)t * HW] = sc[t];
     }
-    float* co = ctx + (size_t)b * C * HW + p;
     for (int c = 0; c < C; ++c) {
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) s += pj[c][t] * sc[t];
-        co[(size_t)c * HW] = s;
+        st1<DT>(ctx, img0 + (size_t)c * HW, s);
     }
 }
 
 // backward of the streaming pass.  The d(proj) contribution of a workgroup's 256 pixels is reduced WITHOUT atomics so that
 // the result is bit-reproducible: a butterfly per channel inside each wave, one LDS row per wave, a fixed-order sum of the
 // four rows, and one partial [C][T] slab per workgroup that attn_dproj_reduce_kernel sums in block order.
-template <int TMAX>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ images, const float* __restrict__ proj,
-                                                       const float* __restrict__ attn, const float* __restrict__ dctx,
-                                                       const float* __restrict__ dattn, float scale, float* __restrict__ dimages,
+template <int TMAX, int DT = AGAN_DT_F32>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const void* __restrict__ images, const float* __restrict__ proj,
+                                                       const float* __restrict__ attn, const void* __restrict__ dctx,
+                                                       const float* __restrict__ dattn, float scale, void* __restrict__ dimages,
                                                        float* __restrict__ dproj_part, int C, int T, int HW) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float (*pj)[TMAX] = reinterpret_cast<float (*)[TMAX]>(smem_raw);                               // [kMaxC][TMAX]
@@ -132,20 +132,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         a[t] = (live && t < T) ? attn[((size_t)b * T + t) * HW + pp] : 0.f;
         da[t] = (live && t < T && dattn) ? dattn[((size_t)b * T + t) * HW + pp] : 0.f;
     }
-    const float* dc = dctx ? dctx + (size_t)b * C * HW + pp : nullptr;
+    const bool dc = dctx != nullptr;
+    const size_t base0 = (size_t)b * C * HW + pp;      // element index of (b, channel 0, this pixel) in images / dctx / dimages
     // Both channel loops are LATENCY bound as written one channel at a time (a dependent HBM round trip per iteration, ~6 waves per
     // SIMD to hide it): they run kCU channels per trip with the next trip's loads already in flight.
     constexpr int kCU = 4;
     if (dc) {
         float nx[kCU];
 #pragma unroll
-        for (int j = 0; j < kCU; ++j) nx[j] = (live && j < C) ? dc[(size_t)j * HW] : 0.f;
+        for (int j = 0; j < kCU; ++j) nx[j] = (live && j < C) ? ld1<DT>(dctx, base0 + (size_t)(j) * HW) : 0.f;
         for (int c0 = 0; c0 < C; c0 += kCU) {
             float v[kCU];
 #pragma unroll
             for (int j = 0; j < kCU; ++j) v[j] = nx[j];
 #pragma unroll
-            for (int j = 0; j < kCU; ++j) nx[j] = (live && c0 + kCU + j < C) ? dc[(size_t)(c0 + kCU + j) * HW] : 0.f;
+            for (int j = 0; j < kCU; ++j) nx[j] = (live && c0 + kCU + j < C) ? ld1<DT>(dctx, base0 + (size_t)((c0 + kCU + j)) * HW) : 0.f;
 #pragma unroll
             for (int j = 0; j < kCU; ++j) {
                 if (c0 + j < C) {
@@ -161,8 +162,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     float ds[TMAX];   // gradient w.r.t. the raw (unscaled) score
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) ds[t] = a[t] * (da[t] - dot) * scale;
-    const float* img = images + (size_t)b * C * HW + pp;
-    float* di = dimages + (size_t)b * C * HW + pp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (TMAX == 16) {
         // d(proj)[c][t] = sum over the pixels of dctx[c][p] attn[t][p] + images[c][p] ds[t][p] is a (channels x words x pixels) contraction
@@ -190,8 +189,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const bool on = live && c0 + j < C;
-                ivr[j] = on ? img[(size_t)(c0 + j) * HW] : 0.f;
-                Xw[j * kAttLd + lane] = (on && dc) ? dc[(size_t)(c0 + j) * HW] : 0.f;
+                ivr[j] = on ? ld1<DT>(images, base0 + (size_t)((c0 + j)) * HW) : 0.f;
+                Xw[j * kAttLd + lane] = (on && dc) ? ld1<DT>(dctx, base0 + (size_t)((c0 + j)) * HW) : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                     float s = 0.f;
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
-                    if (live) di[(size_t)c * HW] = s;
+                    if (live) st1<DT>(dimages, base0 + (size_t)(c) * HW, s);
                 }
             }
             wave_lds_sync();
@@ -221,8 +220,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     float ivn[kCU], dvn[kCU];
     #pragma unroll
         for (int j = 0; j < kCU; ++j) {
-            ivn[j] = (live && j < C) ? img[(size_t)j * HW] : 0.f;
-            dvn[j] = (live && dc && j < C) ? dc[(size_t)j * HW] : 0.f;
+            ivn[j] = (live && j < C) ? ld1<DT>(images, base0 + (size_t)(j) * HW) : 0.f;
+            dvn[j] = (live && dc && j < C) ? ld1<DT>(dctx, base0 + (size_t)(j) * HW) : 0.f;
         }
         for (int c0 = 0; c0 < C; c0 += kCU) {
             float ivc[kCU], dvc[kCU];
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     #pragma unroll
             for (int j = 0; j < kCU; ++j) {
                 const bool more = live && c0 + kCU + j < C;
-                ivn[j] = more ? img[(size_t)(c0 + kCU + j) * HW] : 0.f;
-                dvn[j] = (more && dc) ? dc[(size_t)(c0 + kCU + j) * HW] : 0.f;
+                ivn[j] = more ? ld1<DT>(images, base0 + (size_t)((c0 + kCU + j)) * HW) : 0.f;
+                dvn[j] = (more && dc) ? ld1<DT>(dctx, base0 + (size_t)((c0 + kCU + j)) * HW) : 0.f;
             }
     #pragma unroll
             for (int j = 0; j < kCU; ++j) {
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 float s = 0.f;
     #pragma unroll
                 for (int t = 0; t < TMAX; ++t) s += ds[t] * pj[c][t];
-                if (live) di[(size_t)c * HW] = s;
+                if (live) st1<DT>(dimages, base0 + (size_t)(c) * HW, s);
     #if AGAN_ATTN_ABLATE != 1
                 float part[TMAX];
     #pragma unroll
@@ -307,7 +306,13 @@ extern "C" {
 
 int agan_attn_fwd(const float* images, const float* words, const float* w, const int64_t* mask, float scale, float* proj,
                   float* ctx, float* attn, int B, int C, int E, int T, int HW, void* stream) {
+    return agan_attn_fwd_dt(images, words, w, mask, scale, proj, ctx, attn, B, C, E, T, HW, stream, AGAN_DT_F32);
+}
+
+int agan_attn_fwd_dt(const void* images, const float* words, const float* w, const int64_t* mask, float scale, float* proj,
+                     void* ctx, float* attn, int B, int C, int E, int T, int HW, void* stream, int dtype) {
     AGAN_REQUIRE(images && words && w && mask && proj && ctx && attn, "attn_fwd: null pointer");
+    AGAN_REQUIRE(dtype == AGAN_DT_F32 || dtype == AGAN_DT_BF16 || dtype == AGAN_DT_F16, "attn_fwd: storage type %d", dtype);
     AGAN_REQUIRE(B > 0 && C > 0 && E > 0 && T > 0 && HW > 0, "attn_fwd: non-positive dimension");
     AGAN_REQUIRE(C <= kMaxC, "attn_fwd: nc_in %d > %d", C, kMaxC);
     AGAN_REQUIRE(T <= 64, "attn_fwd: seq_len %d > 64", T);
@@ -316,9 +321,16 @@ int agan_attn_fwd(const float* images, const float* words, const float* w, const
     else if (T <= 32) hipLaunchKernelGGL((attn_proj_kernel<32>), dim3(cdiv(B * C, 4)), dim3(256), 0, st, words, w, proj, B, C, E, T);
     else hipLaunchKernelGGL((attn_proj_kernel<64>), dim3(cdiv(B * C, 4)), dim3(256), 0, st, words, w, proj, B, C, E, T);
     dim3 grid(cdiv(HW, 256), B);
-    if (T <= 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);
-    else if (T <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);
+#define AGAN_ATTN_FWD(TM)                                                                                                                        \
+    do {                                                                                                                                         \
+        if (dtype == AGAN_DT_BF16) hipLaunchKernelGGL((attn_fwd_kernel<TM, AGAN_DT_BF16>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW); \
+        else if (dtype == AGAN_DT_F16) hipLaunchKernelGGL((attn_fwd_kernel<TM, AGAN_DT_F16>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW); \
+        else hipLaunchKernelGGL((attn_fwd_kernel<TM>), grid, dim3(256), 0, st, images, proj, mask, scale, ctx, attn, C, T, HW);                      \
+    } while (0)
+    if (T <= 16) AGAN_ATTN_FWD(16);
+    else if (T <= 32) AGAN_ATTN_FWD(32);
+    else AGAN_ATTN_FWD(64);
+#undef AGAN_ATTN_FWD
     return check_launch("attn_fwd");
 }
 
@@ -330,7 +342,15 @@ size_t agan_attn_bwd_ws_bytes(int B, int C, int T, int HW) {
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw, int B, int C,
                   int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return agan_attn_bwd_dt(images, words, w, proj, attn, dctx, dattn, scale, dimages, dwords, dw, B, C, E, T, HW, accumulate, ws, ws_bytes,
+                            stream, AGAN_DT_F32);
+}
+
+int agan_attn_bwd_dt(const void* images, const float* words, const float* w, const float* proj, const float* attn,
+                     const void* dctx, const float* dattn, float scale, void* dimages, float* dwords, float* dw, int B, int C,
+                     int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream, int dtype) {
     AGAN_REQUIRE(images && words && w && proj && attn && dimages && dwords && dw && ws, "attn_bwd: null pointer");
+    AGAN_REQUIRE(dtype == AGAN_DT_F32 || dtype == AGAN_DT_BF16 || dtype == AGAN_DT_F16, "attn_bwd: storage type %d", dtype);
     AGAN_REQUIRE(B > 0 && C > 0 && E > 0 && T > 0 && HW > 0, "attn_bwd: non-positive dimension");
     AGAN_REQUIRE(C <= kMaxC && T <= 64, "attn_bwd: nc_in %d / seq_len %d out of range", C, T);
     if (ws_bytes < agan_attn_bwd_ws_bytes(B, C, T, HW)) {
@@ -342,19 +362,26 @@ int agan_attn_bwd(const float* images, const float* words, const float* w, const
     float* part = dproj + (size_t)B * C * T;
     const int nblk = cdiv(HW, 256);
     dim3 grid(nblk, B);
-#define AGAN_ATTN_BWD(TM)                                                                                                            \
+#define AGAN_ATTN_BWD_DT(TM, DT)                                                                                                     \
     do {                                                                                                                             \
-        const size_t smem_ = sizeof(float) * (kMaxC * TM * 5 + (TM == 16 ? 4 * 48 * kAttLd : 0));                                                                         \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TM>),                      \
+        const size_t smem_ = sizeof(float) * (kMaxC * TM * 5 + (TM == 16 ? 4 * 48 * kAttLd : 0));                                    \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TM, DT>),                  \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_);                 \
         (void)attr_;                                                                                                                 \
-        hipLaunchKernelGGL((attn_bwd_kernel<TM>), grid, dim3(256), smem_, st, images, proj, attn, dctx, dattn, scale, dimages, part, \
+        hipLaunchKernelGGL((attn_bwd_kernel<TM, DT>), grid, dim3(256), smem_, st, images, proj, attn, dctx, dattn, scale, dimages, part, \
                            C, T, HW);                                                                                                \
+    } while (0)
+#define AGAN_ATTN_BWD(TM)                                                       \
+    do {                                                                        \
+        if (dtype == AGAN_DT_BF16) AGAN_ATTN_BWD_DT(TM, AGAN_DT_BF16);          \
+        else if (dtype == AGAN_DT_F16) AGAN_ATTN_BWD_DT(TM, AGAN_DT_F16);       \
+        else AGAN_ATTN_BWD_DT(TM, AGAN_DT_F32);                                 \
     } while (0)
     if (T <= 16) AGAN_ATTN_BWD(16);
     else if (T <= 32) AGAN_ATTN_BWD(32);
     else AGAN_ATTN_BWD(64);
 #undef AGAN_ATTN_BWD
+#undef AGAN_ATTN_BWD_DT
     hipLaunchKernelGGL(attn_dproj_reduce_kernel, dim3(cdiv(B * C * T, 256)), dim3(256), 0, st, part, dproj, B, nblk, C * T);
     hipLaunchKernelGGL(attn_bwd_words_kernel, dim3(cdiv(B * E * T + C * E, 256)), dim3(256), 0, st, words, w, dproj, dwords, dw, B, C, E, T, accumulate);
     return check_launch("attn_bwd");

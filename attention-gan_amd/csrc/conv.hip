@@ -57,12 +57,14 @@ __global__ __launch_bounds__(256) void ktable_kernel(int2* __restrict__ tab, int
 #ifndef AGAN_GATHER_WAVES
 #define AGAN_GATHER_WAVES 3
 #endif
-template <int BM, int BN, int WM, int WN>
+// ODT: storage type of `out` and of `lrelu_mask` (AGAN_DT_*; fp32 arithmetic either way -- a 16-bit output is the data gradient or
+// the first-layer output of a network that keeps its activations in 16 bits: rounded once here instead of by a cast kernel)
+template <int BM, int BN, int WM, int WN, int ODT = AGAN_DT_F32>
 __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel(const float* __restrict__ in, const float* __restrict__ wk,
-                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               const float* __restrict__ bias, void* __restrict__ out_v,
                                                                const int2* __restrict__ ktab, const Geom g, const int ksplit,
                                                                const int kchunk, const size_t slab, const int act,
-                                                               const float* __restrict__ lrelu_mask) {
+                                                               const void* __restrict__ lrelu_mask) {
     constexpr int BK = AGAN_GATHER_BK;
     constexpr int NG = 256 / BM;       // wave-uniform k groups for the pixel-major A loads
     constexpr int AK = BK / NG;        // k rows per thread per tile
@@ -246,14 +248,17 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
 
     // ---- epilogue: D[cout][pixel]; lane owns one pixel column, 16 registers = 16 output channels ---
     const size_t ohw = (size_t)g.OH * g.OW;
-    float* dst = (ksplit > 1) ? out + (size_t)split * slab : out;
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    // (a split launch writes fp32 partial slabs whatever ODT is; the slab sum rounds)
+    const bool typed = (ODT != AGAN_DT_F32) && (ksplit == 1);
+    const unsigned esz = typed ? 2u : 4u;
+    float* dst = (ksplit > 1) ? static_cast<float*>(out_v) + (size_t)split * slab : static_cast<float*>(out_v);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(dst, (size_t)g.B * g.Cout * ohw * esz);
     const bool add_bias = (bias != nullptr) && (ksplit == 1);
     const bool lrelu = (act == AGAN_ACT_LRELU) && (ksplit == 1);          // fused LeakyReLU(0.2) (a split launch applies it in the slab sum)
     // data-gradient launches: out *= LeakyReLU'(mask) where mask is the tensor the output is the gradient OF (same shape) -- the
     // backward of the activation that produced this conv's input, folded into the epilogue instead of a separate pass
     const bool masked = (lrelu_mask != nullptr) && (ksplit == 1);
-    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : dst, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(masked ? lrelu_mask : (const void*)dst, (size_t)g.B * g.Cout * ohw * esz);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mo = m0 + wm * WTM + tm * 32 + l31;
@@ -270,9 +275,21 @@ __global__ __launch_bounds__(256, AGAN_GATHER_WAVES) void conv_gather_f32_kernel
                 float v = acc[tn][tm][r];
                 if (add_bias) v += bias[min(n, g.Cout - 1)];
                 if (lrelu) v = v > 0.f ? v : 0.2f * v;
-                const unsigned off = (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * 4u : kOOB;
-                if (masked) v = buf_load(rmask, off) > 0.f ? v : 0.2f * v;
-                buf_store(rout, off, v);
+                const unsigned off = (pvalid & (n < g.Cout)) ? (pixoff + (unsigned)n * (unsigned)ohw) * esz : kOOB;
+                if (ODT != AGAN_DT_F32 && typed) {
+                    if (masked) {
+                        const unsigned short mh = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rmask, off, 0, 0);
+                        const float mv = ODT == AGAN_DT_BF16 ? __uint_as_float((unsigned)mh << 16) : (float)__builtin_bit_cast(_Float16, mh);
+                        v = mv > 0.f ? v : 0.2f * v;
+                    }
+                    unsigned short h;
+                    if (ODT == AGAN_DT_BF16) h = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    else h = __builtin_bit_cast(unsigned short, (_Float16)v);
+                    __builtin_amdgcn_raw_buffer_store_b16((short)h, rout, off, 0, 0);
+                } else {
+                    if (masked) v = buf_load(rmask, off) > 0.f ? v : 0.2f * v;
+                    buf_store(rout, off, v);
+                }
             }
         }
     }
@@ -357,11 +374,18 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel_t(const float* __restric
 #define sum_slabs_kernel sum_slabs_kernel_t<AGAN_DT_F32>      /* the fp32 form every fp32-storage call site uses */
 
 template <int BN, int WM, int WN>
-void launch_gather(const float* in, const float* wk, const float* bias, float* dst, const int2* ktab, const Geom& g,
-                   const GatherPlan& p, int act, const float* lrelu_mask, hipStream_t st) {
+void launch_gather(const float* in, const float* wk, const float* bias, void* dst, const int2* ktab, const Geom& g,
+                   const GatherPlan& p, int act, const void* lrelu_mask, hipStream_t st, int out_dtype = AGAN_DT_F32) {
     dim3 grid(p.mtiles, p.ntiles, p.ncls * p.ksplit);
-    hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
-                       p.kchunk, p.slab, act, lrelu_mask);
+    if (out_dtype == AGAN_DT_BF16)
+        hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN, AGAN_DT_BF16>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
+                           p.kchunk, p.slab, act, lrelu_mask);
+    else if (out_dtype == AGAN_DT_F16)
+        hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN, AGAN_DT_F16>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
+                           p.kchunk, p.slab, act, lrelu_mask);
+    else
+        hipLaunchKernelGGL((conv_gather_f32_kernel<128, BN, WM, WN>), grid, dim3(256), 0, st, in, wk, bias, dst, ktab, g, p.ksplit,
+                           p.kchunk, p.slab, act, lrelu_mask);
 }
 
 // ================================================================================================
@@ -906,10 +930,21 @@ static bool p16_takes(const Geom& g, int prec, int in_dtype, int out_dtype, P16P
     return p.ok != 0;
 }
 
+static bool dt16(int dt) { return dt == AGAN_DT_BF16 || dt == AGAN_DT_F16; }
+// the fp32-arithmetic kernels with typed storage: the <= 4-output-channel kernels read a 16-bit input (fp32 output), the k-table
+// MFMA kernels write a 16-bit output (fp32 input)
+static bool f32_kernel_takes(const Geom& g, const agan_conv_geom* gg, int prec, int in_dtype, int out_dtype) {
+    if (agan_conv_effective_prec(gg, prec) != AGAN_PREC_F32) return false;
+    if (small_n_gather_supported(g)) return (in_dtype == AGAN_DT_F32 || dt16(in_dtype)) && out_dtype == AGAN_DT_F32 && !(g.RS == 1 && g.IH == 1 && g.IW == 1 && in_dtype != AGAN_DT_F32);
+    return in_dtype == AGAN_DT_F32 && (out_dtype == AGAN_DT_F32 || dt16(out_dtype));
+}
+
 int agan_conv_gather_dt_supported(const agan_conv_geom* gg, int prec, int in_dtype, int out_dtype) {
     if (check_geom(gg)) return 0;
     if (in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32) return 1;
-    return p16_takes(make_geom(gg), prec, in_dtype, out_dtype, nullptr) ? 1 : 0;
+    const Geom g = make_geom(gg);
+    if (p16_takes(g, prec, in_dtype, out_dtype, nullptr)) return 1;
+    return f32_kernel_takes(g, gg, agan_conv_effective_prec(gg, prec), in_dtype, out_dtype) ? 1 : 0;
 }
 
 int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, void* out_v, const agan_conv_geom* gg, const int32_t* ktable,
@@ -954,7 +989,7 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
             return AGAN_OK;
         }
     }
-    AGAN_REQUIRE(in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32,
+    AGAN_REQUIRE((in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32) || f32_kernel_takes(g, gg, prec, in_dtype, out_dtype),
                  "conv_gather: 16-bit activation storage (%d -> %d) is not available for this geometry / precision %d "
                  "(agan_conv_gather_dt_supported)", in_dtype, out_dtype, prec);
     const float* in = static_cast<const float*>(in_v);
@@ -984,7 +1019,7 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
     }
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {
         timer_begin(st);
-        launch_gather_small_n(in, wk, bias, out, g, st);
+        launch_gather_small_n(in_v, wk, bias, out, g, st, in_dtype);
         timer_end(st);
         return check_launch("conv_gather/small_n");
     }
@@ -993,18 +1028,22 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
         set_error("conv_gather: workspace %zu < %zu", ws_bytes, p.ws_bytes);
         return AGAN_EWORKSPACE;
     }
-    float* dst = p.ksplit > 1 ? static_cast<float*>(ws) : out;
+    void* dst = p.ksplit > 1 ? ws : out_v;
     timer_begin(st);
-    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
-    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
-    else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask, st);
+    if (p.bn == 128) launch_gather<128, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask_v, st, out_dtype);
+    else if (p.bn == 64) launch_gather<64, 2, 2>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask_v, st, out_dtype);
+    else launch_gather<32, 4, 1>(in, wk, bias, dst, ktab, g, p, act, lrelu_mask_v, st, out_dtype);
     timer_end(st);
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
         const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
-                           bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask);
+#define AGAN_SUM_DT(DT) hipLaunchKernelGGL(sum_slabs_kernel_t<DT>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, \
+                                           p.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v, (float*)nullptr)
+        if (out_dtype == AGAN_DT_F32) AGAN_SUM_DT(AGAN_DT_F32);
+        else if (out_dtype == AGAN_DT_BF16) AGAN_SUM_DT(AGAN_DT_BF16);
+        else AGAN_SUM_DT(AGAN_DT_F16);
+#undef AGAN_SUM_DT
         return check_launch("conv_gather/sum_slabs");
     }
     return AGAN_OK;
@@ -1035,6 +1074,11 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
 int agan_conv_wgrad_dt_supported(const agan_conv_geom* gg, int pack_mode, int prec, int x_dtype, int dy_dtype) {
     if (check_geom(gg)) return 0;
     if (x_dtype == AGAN_DT_F32 && dy_dtype == AGAN_DT_F32) return 1;
+    {   // the <= 4-output-channel weight gradient (RGB heads) reads a 16-bit x
+        const Geom g = make_geom(gg);
+        if (pack_mode == AGAN_PACK_FWD && small_n_wgrad_supported(g) && agan_conv_wgrad_effective_prec(gg, pack_mode, prec) == AGAN_PREC_F32)
+            return (dt16(x_dtype) && dy_dtype == AGAN_DT_F32) ? 1 : 0;
+    }
     if (prec != AGAN_PREC_BF16 && prec != AGAN_PREC_F16) return 0;
     const int want = prec == AGAN_PREC_BF16 ? AGAN_DT_BF16 : AGAN_DT_F16;
     if ((x_dtype != AGAN_DT_F32 && x_dtype != want) || (dy_dtype != AGAN_DT_F32 && dy_dtype != want)) return 0;
@@ -1099,7 +1143,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
         }
         float* part = static_cast<float*>(ws);
         timer_begin(st);
-        launch_wgrad_small_n(x, dy, part, g, sp, st);
+        launch_wgrad_small_n(x_v, dy, part, g, sp, st, x_dtype);
         timer_end(st);
         const size_t n = (size_t)g.Cout * g.K;
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, part, sp.nchunk,

@@ -246,10 +246,10 @@ struct SmallWgradPlan {
     size_t slab, ws_bytes;
 };
 bool small_n_gather_supported(const Geom& g);
-void launch_gather_small_n(const float* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st);
+void launch_gather_small_n(const void* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st, int in_dtype = AGAN_DT_F32);
 bool small_n_wgrad_supported(const Geom& g);
 SmallWgradPlan plan_wgrad_small_n(const Geom& g);
-void launch_wgrad_small_n(const float* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st);
+void launch_wgrad_small_n(const void* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st, int x_dtype = AGAN_DT_F32);
 
 // ---- patch-resident 16-bit MFMA kernels (conv_patch.hip): AGAN_PREC_BF16 / F16 / BF16X3 / BF16X6 ------------------------------
 // taps of the GATHER geometry a pack mode is used with (R x S per class, input step SY): a 3x3 forward conv is the stride-1

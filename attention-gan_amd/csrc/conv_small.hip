@@ -12,8 +12,9 @@ using namespace agan::conv;
 namespace {
 
 // forward / dgrad, Cout <= 4.  RS = taps per class (1, 4, 9, 16), S = tap columns.
-template <int RS, int S>
-__global__ __launch_bounds__(256) void conv_small_n_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+// IDT: storage type of `in` (AGAN_DT_*)
+template <int RS, int S, int IDT = AGAN_DT_F32>
+__global__ __launch_bounds__(256) void conv_small_n_kernel(const void* __restrict__ in, const float* __restrict__ wk,
                                                            const float* __restrict__ bias, float* __restrict__ out, const Geom g) {
     // XCD-aware order (conv_common.h): neighbouring pixel blocks share halo rows and the parity classes of a block read the same
     // window -- position F = (pixel block, class), each XCD a contiguous run.  These layers are HBM-bound, so the re-fetches the
@@ -35,17 +36,23 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(const float* __restri
     for (int t = 0; t < RS; ++t) {
         const int dy = (t / S) * g.DY, dx = (t % S) * g.DY;
         const bool ok = valid & ((unsigned)(iy0 + dy) < (unsigned)g.IH) & ((unsigned)(ix0 + dx) < (unsigned)g.IW);
-        off[t] = ok ? (unsigned)(pix0 + dy * g.IW + dx) * 4u : kOOB;
+        off[t] = ok ? (unsigned)(pix0 + dy * g.IW + dx) * (IDT == AGAN_DT_F32 ? 4u : 2u) : kOOB;
     }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    constexpr unsigned IE = IDT == AGAN_DT_F32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (size_t)g.B * g.Cin * ihw * IE);
     const float* wc = wk + (size_t)cls * g.K * g.Nld;      // packed fp32 weights [K][Nld]: row k starts with the <= 4 live columns
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int c = 0; c < g.Cin; ++c) {
-        const unsigned soff = (unsigned)(c * ihw) * 4u;
+        const unsigned soff = (unsigned)(c * ihw) * IE;
         const float* wr = wc + (size_t)c * RS * g.Nld;
 #pragma unroll
         for (int t = 0; t < RS; ++t) {
-            const float v = buf_load_s(rin, off[t], soff);
+            float v;
+            if (IDT == AGAN_DT_F32) v = buf_load_s(rin, off[t], soff);
+            else {
+                const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, off[t], soff, 0);
+                v = IDT == AGAN_DT_BF16 ? __uint_as_float((unsigned)h << 16) : (float)__builtin_bit_cast(_Float16, h);
+            }
             const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)t * g.Nld);      // wave-uniform -> s_load_dwordx4
             a0 += v * w.x; a1 += v * w.y; a2 += v * w.z; a3 += v * w.w;
         }
@@ -85,8 +92,8 @@ __global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __rest
 
 // weight gradient of a direct (OS = 1) conv with Cout <= 4: one workgroup = one input channel x one chunk of pixels.
 // Each lane walks its pixels with RS*Cout running sums in registers; they meet once per workgroup (wave shuffle + LDS).
-template <int RS, int S>
-__global__ __launch_bounds__(256) void wgrad_small_n_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+template <int RS, int S, int XDT = AGAN_DT_F32>
+__global__ __launch_bounds__(256) void wgrad_small_n_kernel(const void* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                             const Geom g, const int pchunk, const size_t slab) {
     __shared__ float red[4][RS * 4];
     // XCD-aware order: the Cin workgroups of one pixel chunk all read the chunk's dY -- keep them on one XCD
@@ -94,8 +101,9 @@ __global__ __launch_bounds__(256) void wgrad_small_n_kernel(const float* __restr
     const int c = F % (int)gridDim.x, chunk = F / (int)gridDim.x;
     const int pbeg = chunk * pchunk, pend = min(g.Mtot, pbeg + pchunk);
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
-    const unsigned soff = (unsigned)(c * ihw) * 4u;
+    constexpr unsigned XE = XDT == AGAN_DT_F32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * XE);
+    const unsigned soff = (unsigned)(c * ihw) * XE;
     float acc[RS][4];
 #pragma unroll
     for (int t = 0; t < RS; ++t)
@@ -114,7 +122,12 @@ __global__ __launch_bounds__(256) void wgrad_small_n_kernel(const float* __restr
         for (int t = 0; t < RS; ++t) {
             const int ddy = (t / S) * g.DY, ddx = (t % S) * g.DY;
             const bool ok = ((unsigned)(iy0 + ddy) < (unsigned)g.IH) & ((unsigned)(ix0 + ddx) < (unsigned)g.IW);
-            const float v = buf_load_s(rx, ok ? (unsigned)(pix0 + ddy * g.IW + ddx) * 4u : kOOB, soff);
+            float v;
+            if (XDT == AGAN_DT_F32) v = buf_load_s(rx, ok ? (unsigned)(pix0 + ddy * g.IW + ddx) * 4u : kOOB, soff);
+            else {
+                const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, ok ? (unsigned)(pix0 + ddy * g.IW + ddx) * 2u : kOOB, soff, 0);
+                v = XDT == AGAN_DT_BF16 ? __uint_as_float((unsigned)h << 16) : (float)__builtin_bit_cast(_Float16, h);
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[t][n] += v * d[n];
         }
@@ -146,18 +159,25 @@ bool small_n_gather_supported(const Geom& g) {
     return g.RS == 1 || g.RS == 4 || g.RS == 9 || g.RS == 16;
 }
 
-void launch_gather_small_n(const float* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st) {
-    if (g.RS == 1 && g.IH == 1 && g.IW == 1 && g.OS == 1 && g.SY == 1 && g.OY0 == 0) {       // a linear layer: one row per workgroup
-        hipLaunchKernelGGL(linear_small_n_kernel, dim3(g.Mtot), dim3(256), 0, st, in, wk, bias, out, g.K, g.Nld, g.Cout);
+void launch_gather_small_n(const void* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st, int in_dtype) {
+    if (g.RS == 1 && g.IH == 1 && g.IW == 1 && g.OS == 1 && g.SY == 1 && g.OY0 == 0) {       // a linear layer: one row per workgroup (fp32 only)
+        hipLaunchKernelGGL(linear_small_n_kernel, dim3(g.Mtot), dim3(256), 0, st, static_cast<const float*>(in), wk, bias, out, g.K, g.Nld, g.Cout);
         return;
     }
     dim3 grid(cdiv(g.Mtot, 256), g.OS * g.OS);
+#define AGAN_SN(RS_, S_)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (in_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_, AGAN_DT_BF16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
+        else if (in_dtype == AGAN_DT_F16) hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_, AGAN_DT_F16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
+        else hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_>), grid, dim3(256), 0, st, in, wk, bias, out, g);                              \
+    } while (0)
     switch (g.RS) {
-        case 1: hipLaunchKernelGGL((conv_small_n_kernel<1, 1>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
-        case 4: hipLaunchKernelGGL((conv_small_n_kernel<4, 2>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
-        case 9: hipLaunchKernelGGL((conv_small_n_kernel<9, 3>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
-        default: hipLaunchKernelGGL((conv_small_n_kernel<16, 4>), grid, dim3(256), 0, st, in, wk, bias, out, g); break;
+        case 1: AGAN_SN(1, 1); break;
+        case 4: AGAN_SN(4, 2); break;
+        case 9: AGAN_SN(9, 3); break;
+        default: AGAN_SN(16, 4); break;
     }
+#undef AGAN_SN
 }
 
 bool small_n_wgrad_supported(const Geom& g) { return g.Cout <= 4 && g.OS == 1 && g.R == 3 && g.S == 3 && g.Mtot >= 4096; }
@@ -172,8 +192,10 @@ SmallWgradPlan plan_wgrad_small_n(const Geom& g) {
     return p;
 }
 
-void launch_wgrad_small_n(const float* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st) {
-    hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+void launch_wgrad_small_n(const void* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st, int x_dtype) {
+    if (x_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3, AGAN_DT_BF16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+    else if (x_dtype == AGAN_DT_F16) hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3, AGAN_DT_F16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+    else hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
 }
 
 }  // namespace conv

@@ -240,6 +240,13 @@ size_t agan_attn_bwd_ws_bytes(int B, int C, int T, int HW);
 int agan_attn_bwd(const float* images, const float* words, const float* w, const float* proj, const float* attn,
                   const float* dctx, const float* dattn, float scale, float* dimages, float* dwords, float* dw,
                   int B, int C, int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* the same two calls with typed activation storage: `images`, `ctx`, `dctx` and `dimages` have `dtype` (AGAN_DT_*); the attention
+ * map, the projection and all arithmetic stay fp32 */
+int agan_attn_fwd_dt(const void* images, const float* words, const float* w, const int64_t* mask, float scale, float* proj,
+                     void* ctx, float* attn, int B, int C, int E, int T, int HW, void* stream, int dtype);
+int agan_attn_bwd_dt(const void* images, const float* words, const float* w, const float* proj, const float* attn,
+                     const void* dctx, const float* dattn, float scale, void* dimages, float* dwords, float* dw, int B, int C,
+                     int E, int T, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream, int dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * DAMSM losses: WordsLoss.get_loss (losses/words_loss.py:29-102, which loops func_attention

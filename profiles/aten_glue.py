@@ -17,6 +17,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 HF = importlib.import_module("attention-gan_amd.backend.functional")
+LIB = importlib.import_module("attention-gan_amd.backend.lib")
+if os.environ.get("AGAN_GLUE_MODE"):          # e.g. AGAN_GLUE_MODE=bf16 [AGAN_GLUE_STORAGE=bf16]
+    HF.set_precision(LIB.PRECISIONS[os.environ["AGAN_GLUE_MODE"]])
+    HF.set_activation_storage(os.environ.get("AGAN_GLUE_STORAGE"))
 dev = torch.device("cuda", 0)
 step = bench.build(dev, 24, HF)
 words, sent, lens, reals = bench.synthetic_batch(dev, 24, seed=1234)
@@ -40,7 +44,7 @@ for ev in prof.events():
             frame = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
             frame = frame[-110:]
             break
-    key = (ev.name, frame)
+    key = (ev.name, frame) if ev.name != "aten::copy_" else (ev.name, str(ev.input_shapes)[:60])
     by[key][0] += 1
     by[key][1] += ev.device_time_total
     by[key][2].add(str(ev.input_shapes)[:80])

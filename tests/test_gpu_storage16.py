@@ -165,3 +165,31 @@ def test_batchnorm_with_16bit_storage_vs_oracle(mode, act, B, C, H, res, x16):
     assert_close(xd.grad.float(), xr.grad, 3 * ulp if x16 else 1e-4, "dx")
     assert_close(gd.grad, p["bn.weight"].grad, 1e-4, "dgamma")
     assert_close(bd.grad, p["bn.bias"].grad, 1e-4, "dbeta")
+
+
+def test_attention_with_16bit_storage_vs_oracle(mode):
+    """word-context attention reading 16-bit image features and writing a 16-bit context (agan_attn_*_dt): forward against the
+    oracle on the widened values within one output rounding (the attention map stays fp32: tight), backward -- d(images) stored in
+    16 bits, d(words) and d(conv1) fp32 -- within two roundings."""
+    name, tdt, ulp = mode
+    g = torch.Generator().manual_seed(11)
+    B, C, E, T, H = 3, 32, 48, 10, 24
+    q = lambda t: t.to(tdt).float()
+    images, words = q(torch.randn(B, C, H, H, generator=g)), torch.randn(B, E, T, generator=g)
+    w = torch.randn(C, E, 1, 1, generator=g) / E ** 0.5
+    mask = O.make_mask([10, 4, 7])
+    ir, wr, cr = images.clone().requires_grad_(True), words.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ctx_r, attn_r = O.attention_module(ir, wr, cr, mask)
+    gy = q(probe(ctx_r.shape, 0.4))
+    (ctx_r * gy).sum().backward()
+    idv = images.to(tdt).to(DEV).requires_grad_(True)
+    wd, cd = words.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    ctx_d, attn_d = HF.attention(idv, wd, cd, mask.to(DEV))
+    assert ctx_d.dtype == tdt and attn_d.dtype == torch.float32
+    ctx_d.backward(gy.to(DEV).to(tdt))
+    assert_close(attn_d, attn_r, 1e-4, "attention map")
+    assert_close(ctx_d.float(), ctx_r, 1.5 * ulp, "context")
+    assert idv.grad.dtype == tdt
+    assert_close(idv.grad.float(), ir.grad, 3 * ulp, "d images")
+    assert_close(wd.grad, wr.grad, 1e-4, "d words")
+    assert_close(cd.grad, cr.grad, 1e-4, "d conv1")
