@@ -305,6 +305,9 @@ def main():
                     help="launch mode of the step: captured HIP graph replay or eager (auto: at 1 GPU probe both in the untimed warm-up and keep "
                          "the faster; eager under torch.distributed).  segments = nine HIP graphs with the gradient exchange launched "
                          "between them (GanTrainStep.capture_segments): the graph form that also works under torch.distributed")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run the three discriminator updates on ONE stream (profiling aid: per-kernel PMC counters of a rocprofv3 pass are "
+                         "diluted when kernels of different streams share the chip; the headline run overlaps them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short side measurements reported beside the headline (random caption lengths, the fp32-MFMA mode, "
@@ -356,6 +359,8 @@ def main():
             raise SystemExit(f"--storage {args.storage} needs --precision {args.storage} (the storage type is the MFMA operand type)")
         HF.set_activation_storage(args.storage)
     step = build(dev, args.batch, HF, args.image_encoder)
+    if args.single_stream:
+        step.overlap_discriminators = False
     words, sent, lens, reals = synthetic_batch(dev, args.batch, seed=1234 + rank)
     timer = ConvTimer(importlib.import_module("attention-gan_amd.backend.lib"), args.precision)
     HF.set_launch_observer(timer)
@@ -477,7 +482,7 @@ def main():
                        "seq_len": T, "image_encoder": ("frozen stand-in plug-in (pool+projection): the timed step is the hot path of SURVEY §8d, which "
                                                        "prices the third-party trunk separately" if args.image_encoder == "standin" else
                                                        "frozen Inception-v3-shaped trunk (random weights) on stock MIOpen convs, fwd + dgrad in the timed step"),
-                       "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}",
+                       "text_encoder": "bypassed (frozen; N(0,1) embeddings)", "parallelism": f"dp{world}", "discriminator_streams": 1 if args.single_stream else 3,
                        "launch": ("hip-graph segments + eager gradient exchange" if args.graph == "segments" else "hip-graph replay") if use_graph else "eager",
                        "losses_finite": finite},
             "roofline": roofline,

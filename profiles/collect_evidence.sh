@@ -11,8 +11,10 @@ case $MODE in f16*) LOWC=SQ_INSTS_VALU_MFMA_MOPS_F16;; *) LOWC=SQ_INSTS_VALU_MFM
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE --storage $STORAGE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${TAG}_stats -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_mfma -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_fetch -o p -- $B > /dev/null 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_write -o p -- $B > /dev/null 2>&1 &&
+# (the counter passes run the three discriminator updates on ONE stream: a kernel's counters are per dispatch, and kernels of different
+#  streams sharing the chip dilute each other's busy fractions; the kernel-time shares come from the pass above, which overlaps them)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_mfma -o p -- $B --single-stream > /dev/null 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_fetch -o p -- $B --single-stream > /dev/null 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_write -o p -- $B --single-stream > /dev/null 2>&1 &&
 cd $R && python3 profiles/make_counters.py gpurun_out/ev_${TAG} gpurun_out ${TAG} > gpurun_out/ev_${TAG}_summary.txt 2>&1
 tail -3 gpurun_out/ev_${TAG}_summary.txt

@@ -90,7 +90,8 @@ def read_pass(directory):
     with open(files[0], newline="") as f:
         for row in csv.DictReader(f):
             d = per_dispatch.setdefault(row["Dispatch_Id"], {"kernel": row["Kernel_Name"], "t0": int(row["Start_Timestamp"]),
-                                                             "t1": int(row["End_Timestamp"]), "c": {}})
+                                                             "t1": int(row["End_Timestamp"]), "c": {},
+                                                             "grid": str(int(row.get("Grid_Size", "0") or 0) // 256)})
             d["c"][row["Counter_Name"]] = d["c"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     return per_dispatch
 
@@ -139,6 +140,27 @@ def main():
         w.writerow(["kernel_family", "launches", "avg_us", "pct_of_kernel_time", "mfma_util_pct", "mfma_mops_per_launch",
                     "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s"])
         w.writerows(rows)
+    # per LAYER rows for the row-block gathers: one row per (kernel instance, grid), i.e. per layer shape -- the family average above mixes
+    # 0.4 ms layers with 15 us ones
+    layers = {}
+    for d in mfma.values():
+        if "conv_p16_kernel<" not in d["kernel"]:
+            continue
+        inst = d["kernel"].split("conv_p16_kernel<")[1].split(">")[0]
+        key = (inst, d.get("grid", ""))
+        L = layers.setdefault(key, {"n": 0, "ns": 0, "busy": 0.0, "gui": 0.0})
+        L["n"] += 1
+        L["ns"] += d["t1"] - d["t0"]
+        L["busy"] += d["c"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        L["gui"] += d["c"].get("GRBM_GUI_ACTIVE", 0.0)
+    if layers:
+        with open(os.path.join(out_dir, f"{tag}_p16_layer_counters.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["conv_p16_kernel<ET, GK (0 3x3 | 1 2x2-class | 2 4x4-s2), BN, IN16, OUT16, NI[, PX2]>", "grid (workgroups x 256 threads)", "launches",
+                        "avg_us", "total_ms", "mfma_util_pct"])
+            for (inst, grid), L in sorted(layers.items(), key=lambda kv: -kv[1]["ns"]):
+                w.writerow([inst, grid, L["n"], round(L["ns"] / L["n"] / 1e3, 1), round(L["ns"] / 1e6, 3),
+                            round(100.0 * L["busy"] / (L["gui"] * 128.0), 1) if L["gui"] else ""])
     kernels = {b: {"launches": max(c["nf"], c["nw"]), "fetch_size_raw": round(c["fetch"] / max(1, c["nf"])),
                    "write_size": round(c["write"] / max(1, c["nw"])),
                    "traffic": round(2 * c["fetch"] / max(1, c["nf"]) + c["write"] / max(1, c["nw"]))} for b, c in sorted(conv.items())}
