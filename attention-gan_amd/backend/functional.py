@@ -319,6 +319,21 @@ def effective_precision(g: L.ConvGeom) -> int:
     return hit
 
 
+_EFF_WPREC = {}
+
+
+def wgrad_effective_precision(g: L.ConvGeom, pack_mode: int) -> int:
+    """the arithmetic mode the weight gradient of forward geometry g runs in (include/agan.h: agan_conv_wgrad_effective_prec)"""
+    prec = _PRECISION[0]
+    if prec == L.PREC_F32:
+        return prec
+    key = (prec, pack_mode, g.B, g.Cin, g.IH, g.IW, g.Cout, g.OH, g.OW, g.R, g.S, g.OS, g.SY, g.DY, g.OY[0], g.OY[1])
+    hit = _EFF_WPREC.get(key)
+    if hit is None:
+        hit = _EFF_WPREC[key] = int(L.load().agan_conv_wgrad_effective_prec(byref(g), pack_mode, prec))
+    return hit
+
+
 def packed_weight(w: Tensor, mode: int, cache: Optional[dict] = None, prec: Optional[int] = None) -> Tensor:
     cout, cin, kh, kw = w.shape
     if prec is None:
@@ -392,9 +407,15 @@ _AMAX_ARENA: dict = {}            # device -> [arena tensor, window index, next 
 _AMAX_WINDOW, _AMAX_WINDOWS = 1024, 4
 
 
+def _needs_amax() -> bool:
+    """modes whose kernels want max|x| of the tensors they gather: the fp16 split (every gather and weight gradient) and bf16x6 (its
+    weight gradients run on the fp16-split kernel: include/agan.h, agan_conv_wgrad_effective_prec)"""
+    return _PRECISION[0] in (L.PREC_F16X3, L.PREC_BF16X6)
+
+
 def amax_begin_step(device) -> None:
-    """Open a fresh zeroed window of amax slots for one train step (no-op unless the fp16 split mode is on)."""
-    if _PRECISION[0] != L.PREC_F16X3:
+    """Open a fresh zeroed window of amax slots for one train step (no-op unless a mode that needs them is on)."""
+    if not _needs_amax():
         return
     ent = _AMAX_ARENA.get(device)
     if ent is None:
@@ -436,7 +457,7 @@ _AMAX_FUSE_MIN = 1 << 22      # elements: below this a separate agan_absmax laun
 def _amax_out(t: Tensor) -> Optional[Tensor]:
     """slot for a kernel that is about to produce the LARGE tensor `t` (None unless the fp16 split mode is on): the producer folds
     max|t| into it while it streams the tensor, which saves the consumer conv a second pass over tens of megabytes"""
-    if _PRECISION[0] != L.PREC_F16X3 or t.numel() < _AMAX_FUSE_MIN:
+    if not _needs_amax() or t.numel() < _AMAX_FUSE_MIN:
         return None
     slot = _amax_new(t.device)
     _amax_put(t, slot)
@@ -539,7 +560,10 @@ class _ConvFn(Function):
         x, odt = _gather_types(gf, pe, x, get_activation_storage())       # 16-bit activation storage where the layer offers it
         out = torch.empty((B, Cout, OH, OW), dtype=_TORCH_OF[odt], device=x.device)
         b = _dev(bias.detach(), "conv bias") if bias is not None else None
-        xs = amax_of(x) if pe == L.PREC_F16X3 else None               # (kept for the weight gradient)
+        # the amax slot of x: for the fp16-split gather, and for a weight gradient that runs on the fp16-split kernel (f16x3, bf16x6) --
+        # taken HERE, where x still is the object its producer registered a slot for
+        need_xs = pe == L.PREC_F16X3 or (ctx.needs_input_grad[1] and _needs_amax() and wgrad_effective_precision(gf, pf) == L.PREC_F16X3)
+        xs = amax_of(x) if need_xs else None
         _gather(x, packed_weight(w, pf, cache, pe), b, gf, out, kind, "fwd", act, None, pe, xs)
         ctx.x_scale = xs
         if act == L.ACT_NONE:
@@ -573,7 +597,7 @@ class _ConvFn(Function):
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         pe_d = effective_precision(gd) if ctx.needs_input_grad[0] else L.PREC_F32
         # weight gradient: the mode the library will run it in (the fp16 split needs its operands' amax slots only then)
-        pe_w = L.load().agan_conv_wgrad_effective_prec(byref(gf), pf, _PRECISION[0]) if _PRECISION[0] != L.PREC_F32 else L.PREC_F32
+        pe_w = wgrad_effective_precision(gf, pf)
         scaled_w = want_w and pe_w == L.PREC_F16X3
         dys = amax_of(dy) if (pe_d == L.PREC_F16X3 or scaled_w) else None      # ONE slot of dy serves both gradients
         side = None

@@ -871,17 +871,23 @@ int agan_conv_effective_prec(const agan_conv_geom* g, int prec) {
 }
 
 // the mode a weight gradient of forward geometry g runs in.  Besides the geometries the patch kernels do not take:
-//   * AGAN_PREC_BF16X6 -- fp32-grade by definition, so it may use whichever fp32-grade kernel is faster: the fp32 MFMA kernel
-//     (6.5 vs 10 ms per step at the metric config; -DAGAN_BF16X6_PATCH_WGRAD=1 builds the six-product patch kernel in);
+//   * AGAN_PREC_BF16X6 -- fp32-grade by definition, so it may use whichever fp32-grade kernel is fastest.  Its own six-product patch
+//     kernel is not (three planes of two tensors: 10 vs 6.5 ms per step against the fp32 MFMA kernel; -DAGAN_BF16X6_PATCH_WGRAD=1
+//     builds it in).  Round 3: the two-plane fp16 split (AGAN_PREC_F16X3: 22-bit products, the same full-size parity) is 1.35-2.2x
+//     faster than the fp32 kernel on every layer, so bf16x6 weight gradients run there -- the caller supplies the amax slots of x
+//     and dy exactly as in AGAN_PREC_F16X3 (AGAN_BF16X6_WGRAD_F32=1 in the environment restores the fp32 kernel);
 //   * the folded upsample conv (4 classes of 2x2 taps): its patch weight gradient is slower than the fp32 kernel in EVERY mode
 //     (0.61 / 0.52 vs 0.49 ms at 64x128 -> 64x256; 16 short reductions per tile) -- fp32 products are at least as accurate.
 int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int prec) {
     if (prec == AGAN_PREC_F32 || check_geom(g) || prec_planes(prec) == 0) return AGAN_PREC_F32;
     if (!patch_supported(make_geom(g))) return AGAN_PREC_F32;
-#ifndef AGAN_BF16X6_PATCH_WGRAD
-    if (prec == AGAN_PREC_BF16X6) return AGAN_PREC_F32;
-#endif
     if (pack_mode == AGAN_PACK_UP_FWD) return AGAN_PREC_F32;
+#ifndef AGAN_BF16X6_PATCH_WGRAD
+    if (prec == AGAN_PREC_BF16X6) {
+        static const bool f32wg = getenv("AGAN_BF16X6_WGRAD_F32") != nullptr;
+        return f32wg ? AGAN_PREC_F32 : AGAN_PREC_F16X3;
+    }
+#endif
     return prec;
 }
 
