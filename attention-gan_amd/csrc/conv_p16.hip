@@ -66,8 +66,14 @@ template <> struct GKTraits<2> { static constexpr int R = 4, S = 4, IS = 2, CHS 
 // column-parity classes of 64 lattice points from ONE staged patch.  Its accumulator fragments come in pairs (class px = 0, 1 of the
 // same 32 lattice points), so a lane holds two ADJACENT output pixels and the epilogue writes whole contiguous rows -- as separate
 // class launches every store touched every second pixel (2-byte stores at a 4-byte stride) and the patch was staged twice.
+#ifndef AGAN_P16_OCC
+#define AGAN_P16_OCC 2
+#endif
+#ifndef AGAN_P16_WD
+#define AGAN_P16_WD 0
+#endif
 template <int ET, int GK, int BN, bool IN16, bool OUT16, int NI, bool PX2 = false>
-__global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict__ in, const unsigned short* __restrict__ wk,
+__global__ __launch_bounds__(256, AGAN_P16_OCC) void conv_p16_kernel(const void* __restrict__ in, const unsigned short* __restrict__ wk,
                                                           const float* __restrict__ bias, void* __restrict__ out, const Geom g,
                                                           const P16Plan pp, const int act, const void* __restrict__ lrelu_mask) {
     using T = GKTraits<GK>;
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_p16_kernel(const void* __restrict
 #ifndef AGAN_P16_WD_FULL
 #define AGAN_P16_WD_FULL 0
 #endif
-    constexpr int WD = PX2 ? 4 : ((AGAN_P16_WD_FULL && NI == 1) ? SPS : (SPS == 18 ? 9 : 8));     // (PX2: two fragments per slot)
+    constexpr int WD = AGAN_P16_WD ? (SPS == 18 ? (AGAN_P16_WD == 4 ? 3 : AGAN_P16_WD) : AGAN_P16_WD)
+                                   : (PX2 ? 4 : ((AGAN_P16_WD_FULL && NI == 1) ? SPS : (SPS == 18 ? 9 : 8)));     // (PX2: two fragments per slot)
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;
     static_assert(!PX2 || (GK == 1 && TM >= 2), "PX2: 2x2-tap classes, at least two pixel fragments per wave");
     constexpr int NPX = PX2 ? 2 : 1;                 // column-parity classes per workgroup
