@@ -1071,6 +1071,8 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (patch_supported(gg)) {
         const PatchPlan pp = make_patch_plan(gg);
         a = std::max({a, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16).ws_bytes, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16X6).ws_bytes});
+        const RowsPlan rp = plan_rows_wgrad(gg, AGAN_PREC_BF16, false, false);       // (the plan's split does not depend on planes / storage; one plane: the most geometries)
+        if (rp.ok) a = std::max(a, rp.ws_bytes);
     }
     return a;
 }
@@ -1118,6 +1120,31 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
     hipStream_t st = as_stream(stream);
+    if (prec != AGAN_PREC_F32 && !up) {
+        // the row-resident kernel (conv_wgrows.hip) where it takes the geometry: same slab format, its own pixel split
+        const RowsPlan rp = plan_rows_wgrad(g, prec, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
+        if (rp.ok) {
+            if (rp.ws_bytes > ws_bytes || !ws) {
+                set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, rp.ws_bytes);
+                return AGAN_EWORKSPACE;
+            }
+            float* wsf = static_cast<float*>(ws);
+            float* reduced = rp.psplit > 1 ? wsf + rp.slab * rp.psplit : wsf;
+            AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
+            timer_begin(st);
+            launch_rows_wgrad(x_v, dy_v, wsf, g, rp, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
+            timer_end(st);
+            if (int e = check_launch("conv_wgrad/rows")) return e;
+            if (rp.psplit > 1) {
+                const size_t n = (size_t)g.Cout * rp.Kp;
+                hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, rp.psplit, n,
+                                   rp.slab, (const float*)nullptr, 1, 1, reduced, 0);
+                if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
+            }
+            launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, false, rp.NPH, rp.NT, rp.Kp, accumulate, st);
+            return check_launch("conv_wgrad/unpack");
+        }
+    }
     if (prec != AGAN_PREC_F32) {
         const PatchPlan pp = make_patch_plan(g);
         const PatchWgrad p = plan_patch_wgrad(g, pp, prec);

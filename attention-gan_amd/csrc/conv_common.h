@@ -299,7 +299,27 @@ struct P16Plan {
 P16Plan plan_p16(const Geom& g, bool in16);
 void launch_p16_gather(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int prec, int act,
                        const void* lrelu_mask, hipStream_t st, bool in16, bool out16);
+// ---- row-resident weight gradient (conv_wgrows.hip): conv3x3 s1 / conv4x4 s2, one- and two-plane modes, fp32 or 16-bit storage ------
+struct RowsPlan {
+    int ok, gk, ci2;                    // gk 0: conv3x3 stride 1 (ci2: two 32-channel chunks per workgroup, 64 output channels), 2: conv4x4 stride 2
+    int twl, thl, tbl;                  // log2 of the tile's columns (x positions), dy rows, images: 128 pixels
+    int tiles_x, tiles_y, tiles_b, mtiles;
+    int XR, XRT;                        // x rows per image of a tile (tile rows + halo), per tile
+    int rowb, cpitch;                   // LDS bytes per x row / x channel
+    int halo, NBY, drowb, dpitch;       // dy: halo blocks loaded (image rows wider than the tile); blocks loaded per row; LDS bytes per row / channel
+    int plane_bytes, smem_bytes;        // one operand plane = x part + dy part
+    int nxbl, nxitems, nyitems;         // log2 of the 8-pixel blocks per x row; staging items per tile
+    int bj, jtiles, nchunks, ngroups, psplit, tiles_per_split;
+    int NPH, NT, Kp;                    // K' layout of the result slabs: as PatchPlan / PatchWgrad
+    size_t slab, ws_bytes;
+    FastDiv dXRT, dXR, dNBY;
+};
 int prec_planes(int prec);
+RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16);
+void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, int prec, hipStream_t st,
+                       const float* x_scale, const float* dy_scale, bool x16, bool y16);
+void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, int NPH, int NT, int Kp, int accumulate,
+                               hipStream_t st);
 PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec);
 void launch_patch_wgrad(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
                         hipStream_t st, const float* x_scale = nullptr, const float* dy_scale = nullptr, bool x16 = false, bool y16 = false);

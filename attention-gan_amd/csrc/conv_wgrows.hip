@@ -1,0 +1,414 @@
+// Row-resident weight gradient on the 16-bit matrix cores (round 3): no transposition anywhere.
+//
+//     dw[cout][ci][r][s] = sum over (b, oy, ox)  dy[b][cout][oy][ox] * x[b][ci][IS*oy + r - 1][IS*ox + s - 1]
+//
+// The contraction index of a weight gradient is the PIXEL, and v_mfma_f32_32x32x16 wants 8 consecutive values of the contraction index
+// per lane -- which is exactly what 16 bytes of an NCHW row are.  The patch-resident kernel of conv_patch.hip stages both operands
+// [position][channel] (the forward kernels' layout) and reads them back through the transposing ds_read_b64_tr_b16: 20 LDS reads per
+// 9 MFMAs, every x fragment read by all four waves, two barriers per 128 pixels -- 12 % (one plane) / 20 % (two planes) MFMA-busy in
+// the round-3 profiles.  Here both operands live in LDS the way they live in HBM, [channel][row][column], converted to the operand
+// type once on the way in (16-byte global loads along the rows, 16-byte LDS writes, nothing permuted):
+//   * an x fragment (input channel l31, 8 positions) is ONE aligned ds_read_b128 whatever the tap: the row taps are row offsets, and
+//     the column taps are not taken on this side.  Stride 2 keeps the columns de-interleaved [even | odd]: tap s reads parity (s-1)&1;
+//   * the +-1-position column taps are taken on the dy side: next to its aligned 16-byte block a lane reads the dword before and after
+//     it and builds the three shifted fragments dy[j-1 ..], dy[j ..], dy[j+1 ..] with four v_alignbit_b32 each (unaligned 16-byte LDS
+//     reads serialise per lane on gfx950: profiles/micro/lds_unaligned.hip, 256 vs 33 cycles).  The dy rows carry one halo block on
+//     either side; it is loaded when the image row continues there and stays zero otherwise;
+//   * a wave keeps all its taps in accumulators: 9 MFMAs per 3 x reads + 3 dy reads (3x3), 8 per 4 + 3 (4x4 stride 2).
+// (A first version fetched the dy fragments straight from global memory -- a lane per output channel, 16 bytes each: 64 cache lines
+//  per wave-load, and the texture path, not the matrix core, set the pace: 1.25x over the old kernel instead of the 2x+ of this one.)
+// Column tiles are tiles of the X positions j (a pair (dy[ox], x[j]) is counted in the tile that holds j), row tiles are tiles of the
+// dy rows (x rows carry the halo); everything outside the image is a zero load.
+//
+// Geometry kinds: GK 0  conv3x3 stride 1 pad 1: 4 waves = 4 cout fragments x 9 taps on one 32-channel chunk (CI2: 2 cout fragments x
+//                       2 chunks, for layers with <= 64 output channels);
+//                 GK 2  conv4x4 stride 2 pad 1: 4 waves = 2 cout fragments x 2 kernel-row pairs x 8 taps.
+// 128 pixels per tile, two LDS barriers per tile, the next tile's global loads in flight during the k loop.
+// Output: the same [split][cout][K'] slabs as conv_patch.hip's kernel (K' = ((chunk * NPH + phase) * NT + tap) * 32 + ci), so the slab
+// sum and the OIHW unpack are shared.
+#include "conv_common.h"
+#include "split16.h"
+
+#include <cstdlib>
+#include <cstring>
+
+using namespace agan;
+using namespace agan::conv;
+
+namespace {
+
+__device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }   // (lo >> 16) | (hi << 16)
+
+// 8 stored values (one or two 16-byte blocks) -> NPL planes of (p0 p1) (p2 p3) (p4 p5) (p6 p7)
+template <int ET, int NPL, bool S16, bool SCALED>
+__device__ __forceinline__ void to_planes(const u32x4 (&raw)[S16 ? 1 : 2], float scale, u32x4 (&pl)[NPL]) {
+    if constexpr (S16) {
+        pl[0] = raw[0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned e[NPL];
+            const float a = __uint_as_float(raw[k >> 1][(2 * k) & 3]), b = __uint_as_float(raw[k >> 1][(2 * k + 1) & 3]);
+            if (SCALED) split_pack2<ET, NPL>(a * scale, b * scale, e);
+            else split_pack2<ET, NPL>(a, b, e);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) pl[p][k] = e[p];
+        }
+    }
+}
+
+template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NIY>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
+                                                                 const Geom g, const RowsPlan rp, const float* __restrict__ x_scale,
+                                                                 const float* __restrict__ dy_scale) {
+    constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3 (x_scale / dy_scale: amax slots)
+    static_assert(!(X16 || Y16) || NPL == 1, "16-bit activation storage goes with the one-plane modes");
+    static_assert(!CI2 || GK == 0, "the two-chunk layout is the 3x3 kernel's");
+    float xsc = 1.f, ysc = 1.f, unscale = 1.f;
+    if (SCALED) {
+        float ix, iy;
+        xsc = amax_scale(amax_read(x_scale), &ix);
+        ysc = amax_scale(amax_read(dy_scale), &iy);
+        unscale = ix * iy;
+    }
+    constexpr int IS = GK == 2 ? 2 : 1;
+    constexpr int NWJ = (GK == 2 || CI2) ? 2 : 4;    // cout fragments per workgroup
+    constexpr int BJ = NWJ * 32;
+    constexpr int NCI = CI2 ? 64 : 32;               // input channels per workgroup
+    constexpr int NTW = GK == 2 ? 8 : 9;             // taps per wave
+    constexpr int NB = GK == 2 ? 4 : 3;              // x fragments per k-step and wave
+    constexpr int NK = 8;                            // k-steps per tile (128 pixels)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wj = wave % NWJ, part = wave / NWJ;    // GK 2: kernel rows 2 * part, 2 * part + 1;  CI2: chunk 2 * chunk2 + part
+    const int l31 = lane & 31, lh = lane >> 5;
+    int jt, chunk, split;
+    {
+        int F = xcd_contiguous(linear_block_id(), rp.jtiles * rp.ngroups * rp.psplit);
+        jt = F % rp.jtiles; F /= rp.jtiles;
+        chunk = F % rp.ngroups; split = F / rp.ngroups;           // (CI2: a group is two chunks)
+    }
+    const int j0 = jt * BJ, c0 = chunk * NCI;
+    const int twl = rp.twl, thl = rp.thl, bxl = twl - 3;
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    constexpr unsigned XE = X16 ? 2u : 4u, YE = Y16 ? 2u : 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * XE);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * YE);
+    const int tile_beg = split * rp.tiles_per_split, tile_end = min(rp.mtiles, tile_beg + rp.tiles_per_split);
+    const int rowb = rp.rowb, cpitch = rp.cpitch, drowb = rp.drowb, dpitch = rp.dpitch, plane_bytes = rp.plane_bytes;
+    unsigned char* const xs = lds;                                // [plane][NCI channels][cpitch]
+    unsigned char* const ys = lds + NCI * cpitch;                 // [plane][BJ channels][dpitch]   (a plane = x part + dy part)
+
+    struct Tile { int b0, y0, x0; bool ok; };
+    auto tile_of = [&](int mt) {
+        Tile t;
+        t.ok = mt < tile_end;
+        const int txi = mt % rp.tiles_x, tyi = (mt / rp.tiles_x) % rp.tiles_y, tbi = mt / (rp.tiles_x * rp.tiles_y);
+        t.b0 = tbi << rp.tbl; t.y0 = tyi << thl; t.x0 = txi << twl;
+        return t;
+    };
+
+    // ---- staging items, tile independent parts.  x: (channel, tile x row, 16-byte block of 8 input pixels); dy: (channel, tile row,
+    //      block incl. the halo blocks when the image row continues beyond the tile); blocks fastest: a wave-load walks along rows ----
+    int xi_goff[NIX], xi_tb[NIX], xi_j[NIX], xi_xb[NIX];
+    unsigned xi_lds[NIX];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int e = tid + i * 256;
+        const int xb = e & ((1 << rp.nxbl) - 1), t1 = e >> rp.nxbl;
+        const int ci = rp.dXRT.div(t1), rowi = t1 - ci * rp.XRT;
+        const int tb = rp.dXR.div(rowi), j = rowi - tb * rp.XR;
+        const bool ok = (e < rp.nxitems) & (c0 + ci < g.Cin);
+        xi_goff[i] = ok ? (c0 + ci) * ihw : -1;
+        xi_tb[i] = tb; xi_j[i] = j; xi_xb[i] = xb;
+        xi_lds[i] = (unsigned)(ci * cpitch + rowi * rowb + xb * (IS == 2 ? 8 : 16));
+    }
+    int yi_goff[NIY], yi_row[NIY], yi_blk[NIY];
+    unsigned yi_lds[NIY];
+#pragma unroll
+    for (int i = 0; i < NIY; ++i) {
+        const int e = tid + i * 256;
+        const int t1 = rp.dNBY.div(e), blk = e - t1 * rp.NBY - rp.halo;      // -1 .. TW/8 with the halo, else 0 .. TW/8 - 1
+        const int nn = t1 >> (thl + rp.tbl), rowi = t1 & ((1 << (thl + rp.tbl)) - 1);
+        const bool ok = (e < rp.nyitems) & (j0 + nn < g.Cout);
+        yi_goff[i] = ok ? (j0 + nn) * ohw : -1;
+        yi_row[i] = rowi; yi_blk[i] = blk;
+        yi_lds[i] = (unsigned)(nn * dpitch + rowi * drowb + (blk + 1) * 16);
+    }
+    u32x4 xr[NIX][X16 ? 1 : 2], yr[NIY][Y16 ? 1 : 2];
+    auto load_tile = [&](const Tile& t) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int b = t.b0 + xi_tb[i], iy = IS * t.y0 + xi_j[i] - 1, ix = IS * t.x0 + 8 * xi_xb[i];
+            const bool ok = t.ok & (xi_goff[i] >= 0) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & (ix < g.IW);
+            const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * ihw + iy * g.IW + ix);
+            xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
+            if constexpr (!X16) xr[i][1] = buf_load_u4s(rx, ok ? (e0 + 4u) * XE : kOOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int b = t.b0 + (yi_row[i] >> thl), oy = t.y0 + (yi_row[i] & ((1 << thl) - 1)), ox = t.x0 + 8 * yi_blk[i];
+            const bool ok = t.ok & (yi_goff[i] >= 0) & (b < g.B) & (oy < g.OH) & ((unsigned)ox < (unsigned)g.OW);
+            const unsigned e0 = (unsigned)(yi_goff[i] + b * g.Cout * ohw + oy * g.OW + ox);
+            yr[i][0] = buf_load_u4s(rdy, ok ? e0 * YE : kOOB, 0);
+            if constexpr (!Y16) yr[i][1] = buf_load_u4s(rdy, ok ? (e0 + 4u) * YE : kOOB, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            if (tid + i * 256 >= rp.nxitems) continue;
+            u32x4 pl[NPL];
+            to_planes<ET, NPL, X16, SCALED>(xr[i], xsc, pl);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                unsigned char* d = xs + p * plane_bytes + xi_lds[i];
+                if (IS == 1) {
+                    *reinterpret_cast<u32x4*>(d) = pl[p];
+                } else {
+                    const uint2 ev = make_uint2(__builtin_amdgcn_perm(pl[p][1], pl[p][0], 0x05040100u), __builtin_amdgcn_perm(pl[p][3], pl[p][2], 0x05040100u));
+                    const uint2 od = make_uint2(__builtin_amdgcn_perm(pl[p][1], pl[p][0], 0x07060302u), __builtin_amdgcn_perm(pl[p][3], pl[p][2], 0x07060302u));
+                    *reinterpret_cast<uint2*>(d) = ev;
+                    *reinterpret_cast<uint2*>(d + (rowb >> 1)) = od;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            if (tid + i * 256 >= rp.nyitems) continue;
+            u32x4 pl[NPL];
+            to_planes<ET, NPL, Y16, SCALED>(yr[i], ysc, pl);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(ys + p * plane_bytes + yi_lds[i]) = pl[p];
+        }
+    };
+
+    // ---- fragments of k-step kk: block q = 2 * kk + lh of the tile.  x: channel l31 (of this wave's chunk); dy: output channel l31 of
+    //      this wave's fragment, as its aligned block and the dwords on either side ----
+    const unsigned blane = (unsigned)(((CI2 ? part * 32 : 0) + l31) * cpitch);
+    const unsigned alane = (unsigned)((wj * 32 + l31) * dpitch);
+    struct AF { u32x4 c; unsigned l, r; };
+    auto read_frags = [&](int kk, u32x4 (&bf)[NB][NPL], AF (&af)[NPL]) {
+        const int q = 2 * kk + lh;
+        const int bx = q & ((1 << bxl) - 1), trow = q >> bxl;                    // trow = tb * TH + ty
+        const int ty = trow & ((1 << thl) - 1), tb = trow >> thl;
+        const unsigned off = blane + (unsigned)((tb * rp.XR + IS * ty) * rowb + bx * 16);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            // GK 0: i = kernel row r.  GK 2: i = rr * 2 + column parity, kernel row r = 2 * part + rr
+            const unsigned o = GK == 2 ? off + (unsigned)((2 * part + (i >> 1)) * rowb + (i & 1) * (rowb >> 1)) : off + (unsigned)(i * rowb);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) bf[i][p] = *reinterpret_cast<const u32x4*>(xs + p * plane_bytes + o);
+        }
+        const unsigned ao = alane + (unsigned)(trow * drowb + (bx + 1) * 16);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            const unsigned char* a = ys + p * plane_bytes + ao;
+            af[p].c = *reinterpret_cast<const u32x4*>(a);
+            af[p].l = *reinterpret_cast<const unsigned*>(a - 4);                // positions -2, -1
+            af[p].r = *reinterpret_cast<const unsigned*>(a + 16);               // positions 8, 9
+        }
+    };
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (tile_beg < tile_end) {
+        Tile cur = tile_of(tile_beg);
+        load_tile(cur);
+        // the dy halo blocks are written only where the image row continues: zero the dy planes once
+        for (int o = tid * 16; o < NPL * plane_bytes; o += 256 * 16) {
+            const int r = o % plane_bytes;
+            if (r >= NCI * cpitch) *reinterpret_cast<u32x4*>(lds + o) = u32x4{0u, 0u, 0u, 0u};
+        }
+        lds_barrier();
+        store_tile();
+        lds_barrier();
+        for (int mt = tile_beg; mt < tile_end; ++mt) {
+            const Tile nxt = tile_of(mt + 1);
+            load_tile(nxt);                              // (past the last tile: all-zero range, nothing is fetched)
+            u32x4 bf[2][NB][NPL];
+            AF af[2][NPL];
+            read_frags(0, bf[0], af[0]);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                if (kk + 1 < NK) read_frags(kk + 1, bf[(kk + 1) & 1], af[(kk + 1) & 1]);
+                // the three shifted dy fragments av[0] = dy[j-1 ..], av[1] = dy[j ..], av[2] = dy[j+1 ..]
+                u32x4 av[3][NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    const AF& a = af[kk & 1][p];
+                    const unsigned d[6] = {a.l, a.c[0], a.c[1], a.c[2], a.c[3], a.r};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        av[0][p][k] = alignbit16(d[k + 1], d[k]);
+                        av[1][p][k] = d[k + 1];
+                        av[2][p][k] = alignbit16(d[k + 2], d[k + 1]);
+                    }
+                }
+                const auto& b = bf[kk & 1];
+                if (GK == 0) {
+                    // tap (r, s): dy shifted by 1 - s against the x positions
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma_split<ET, NPL>(av[2 - s], b[r], acc[r * 3 + s]);
+                } else {
+                    // tap (rr, s): s = 0 -> (dy[j+1], odd), 1 -> (dy[j], even), 2 -> (dy[j], odd), 3 -> (dy[j-1], even)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        acc[rr * 4 + 0] = mfma_split<ET, NPL>(av[2], b[rr * 2 + 1], acc[rr * 4 + 0]);
+                        acc[rr * 4 + 1] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 0], acc[rr * 4 + 1]);
+                        acc[rr * 4 + 2] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 1], acc[rr * 4 + 2]);
+                        acc[rr * 4 + 3] = mfma_split<ET, NPL>(av[0], b[rr * 2 + 0], acc[rr * 4 + 3]);
+                    }
+                }
+            }
+            lds_barrier();                               // every wave has read the tile
+            if (mt + 1 < tile_end) {
+                store_tile();
+                lds_barrier();
+            }
+            cur = nxt;
+        }
+    }
+
+    // ---- D[cout][channel of the chunk] per tap -> dst[split][cout][kprime], kprime = ((chunk * NPH + ph) * NT + tap) * 32 + ci ----
+    float* o = dst + (size_t)split * rp.slab;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)g.Cout * rp.Kp * sizeof(float));
+    const int ch = CI2 ? 2 * chunk + part : chunk;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        int kcol;
+        if (GK == 0) kcol = (ch * 9 + t) * 32 + l31;
+        else {
+            const int r = 2 * part + (t >> 2), s = t & 3;
+            const int ph = (r & 1) * 2 + (s & 1), tp = (r >> 1) * 2 + (s >> 1);
+            kcol = ((ch * 4 + ph) * 4 + tp) * 32 + l31;
+        }
+        const bool cok = ch * 32 < g.Cin;                      // (CI2 with an odd number of chunks: the last group's second chunk does not exist)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = j0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            buf_store(ro, (cok && nn < g.Cout) ? (unsigned)(nn * rp.Kp + kcol) * 4u : kOOB, SCALED ? acc[t][r] * unscale : acc[t][r]);
+        }
+    }
+}
+
+int pow2ceil_log_w(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16>
+void launch_rows(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
+    constexpr int NIX = GK == 2 ? 10 : (CI2 ? 8 : 4);
+    constexpr int NIY = GK == 2 ? 6 : (CI2 ? 5 : 10);
+    dim3 grid(p.jtiles, p.ngroups, p.psplit);
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr_;
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY>), grid, dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p, xs, ys);
+}
+template <int ET, int NPL, bool X16, bool Y16>
+void launch_rows_gk(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
+    if (p.gk == 2) launch_rows<ET, NPL, 2, false, X16, Y16>(x, dy, part, g, p, st, xs, ys);
+    else if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16>(x, dy, part, g, p, st, xs, ys);
+    else launch_rows<ET, NPL, 0, false, X16, Y16>(x, dy, part, g, p, st, xs, ys);
+}
+template <int ET>
+void launch_rows_dt(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, bool x16, bool y16) {
+    if (x16 && y16) launch_rows_gk<ET, 1, true, true>(x, dy, part, g, p, st, nullptr, nullptr);
+    else if (x16) launch_rows_gk<ET, 1, true, false>(x, dy, part, g, p, st, nullptr, nullptr);
+    else if (y16) launch_rows_gk<ET, 1, false, true>(x, dy, part, g, p, st, nullptr, nullptr);
+    else launch_rows_gk<ET, 1, false, false>(x, dy, part, g, p, st, nullptr, nullptr);
+}
+
+}  // namespace
+
+namespace agan {
+namespace conv {
+
+// Plan of the row-resident weight gradient for FORWARD geometry g in mode prec (p.ok == 0: the kernel does not take the call).
+RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16) {
+    RowsPlan p;
+    memset(&p, 0, sizeof(p));
+    static const bool off = getenv("AGAN_WG_ROWS_OFF") != nullptr;
+    if (off) return p;
+    const int planes = prec_planes(prec);
+    if (planes < 1 || planes > 2) return p;
+    if ((x16 || y16) && planes != 1) return p;
+    if (g.OS != 1 || g.OY0 != -1 || g.DY != 1) return p;
+    int IS, R;
+    if (g.SY == 1 && g.R == 3 && g.S == 3) { p.gk = 0; IS = 1; R = 3; }
+    else if (g.SY == 2 && g.R == 4 && g.S == 4) { p.gk = 2; IS = 2; R = 4; }
+    else return p;
+    if (g.OW < 8 || (g.OW & 7) || g.IW != g.OW * IS || g.IH != g.OH * IS || g.Cin < 8 || g.Cout < 32) return p;
+    p.ci2 = (p.gk == 0 && g.Cout <= 64) ? 1 : 0;
+    const int tpl = 7;
+    p.twl = std::min(p.gk == 2 ? 5 : 6, pow2ceil_log_w(g.OW));
+    p.thl = std::min(tpl - p.twl, pow2ceil_log_w(g.OH));
+    p.tbl = tpl - p.twl - p.thl;
+    const int TW = 1 << p.twl, TH = 1 << p.thl, TB = 1 << p.tbl;
+    p.tiles_x = cdiv(g.OW, TW);
+    p.tiles_y = cdiv(g.OH, TH);
+    p.tiles_b = cdiv(g.B, TB);
+    p.mtiles = p.tiles_x * p.tiles_y * p.tiles_b;
+    p.XR = IS * (TH - 1) + R;
+    p.XRT = TB * p.XR;
+    p.rowb = IS * TW * 2;
+    // channel pitches = 16 mod 256: the 8 lanes of a ds_read_b128 cycle hit 8 different 16-byte bank groups
+    p.cpitch = (p.XRT * p.rowb + 255) / 256 * 256 + 16;
+    p.halo = p.tiles_x > 1 ? 1 : 0;
+    // a dy row = [left halo block][TW / 8 blocks][right halo block]; rows that never load a halo share it: the right neighbour of a row's last
+    // block is the (always zero) left halo slot of the next row, the last row's is the channel's 16-byte pad
+    p.drowb = (TW / 8 + 1 + p.halo) * 16;
+    p.dpitch = (TB * TH * p.drowb + 255) / 256 * 256 + 16;
+    p.bj = (p.gk == 2 || p.ci2) ? 64 : 128;
+    const int nci = p.ci2 ? 64 : 32;
+    p.plane_bytes = nci * p.cpitch + p.bj * p.dpitch;
+    p.smem_bytes = planes * p.plane_bytes;
+    if (p.smem_bytes > 160 * 1024) return p;
+    p.nxbl = pow2ceil_log_w(IS * TW / 8);
+    p.nxitems = nci * p.XRT << p.nxbl;
+    p.NBY = TW / 8 + 2 * p.halo;
+    p.nyitems = p.bj * TB * TH * p.NBY;
+    if (cdiv(p.nxitems, 256) > (p.gk == 2 ? 10 : (p.ci2 ? 8 : 4)) || cdiv(p.nyitems, 256) > (p.gk == 2 ? 6 : (p.ci2 ? 5 : 10))) return p;
+    p.jtiles = cdiv(g.Cout, p.bj);
+    p.nchunks = cdiv(g.Cin, 32);
+    p.ngroups = cdiv(g.Cin, nci);
+    const int wgs = p.jtiles * p.ngroups;
+    int ps = 1;
+    if (wgs < 512) ps = std::max(1, std::min(512 / wgs, p.mtiles));       // one workgroup per CU is resident: cover the chip about twice
+    p.tiles_per_split = cdiv(p.mtiles, ps);
+    p.psplit = cdiv(p.mtiles, p.tiles_per_split);
+    p.NPH = IS == 2 ? 4 : 1;
+    p.NT = IS == 2 ? 4 : 9;
+    p.Kp = p.nchunks * p.NPH * p.NT * 32;
+    p.slab = ((size_t)g.Cout * p.Kp + 3) / 4 * 4;
+    p.ws_bytes = p.slab * (p.psplit + (p.psplit > 1 ? 1 : 0)) * sizeof(float);      // partial slabs + the reduced one
+    p.dXRT = make_fastdiv((unsigned)p.XRT);
+    p.dXR = make_fastdiv((unsigned)p.XR);
+    p.dNBY = make_fastdiv((unsigned)p.NBY);
+    p.ok = 1;
+    return p;
+}
+
+void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, int prec, hipStream_t st,
+                       const float* x_scale, const float* dy_scale, bool x16, bool y16) {
+    switch (prec) {
+        case AGAN_PREC_BF16: launch_rows_dt<0>(x, dy, part, g, p, st, x16, y16); break;
+        case AGAN_PREC_F16: launch_rows_dt<1>(x, dy, part, g, p, st, x16, y16); break;
+        case AGAN_PREC_BF16X3: launch_rows_gk<0, 2, false, false>(x, dy, part, g, p, st, nullptr, nullptr); break;
+        default: launch_rows_gk<1, 2, false, false>(x, dy, part, g, p, st, x_scale, dy_scale); break;      // AGAN_PREC_F16X3
+    }
+}
+
+}  // namespace conv
+}  // namespace agan

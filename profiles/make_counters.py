@@ -39,7 +39,7 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
     ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
-    ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel"]),
+    ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel", "small_strip_kernel"]),
     ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel"]),
     ("weight packs", ["pack_"]),
     ("absmax (f16x3: max|x| of small tensors)", ["absmax_kernel"]),
@@ -134,11 +134,14 @@ def main():
         traffic = (2 * f["fetch"] / max(1, f["nf"]) + f["write"] / max(1, f["nw"])) if (f["nf"] or f["nw"]) else 0.0
         rows.append([name, f["n"], round(avg_us, 1), round(100.0 * f["ns"] / max(1, total_ns), 2),
                      round(100.0 * f["busy"] / (f["gui"] * 128.0), 1) if f["gui"] else "",
-                     round(f["mops"] / n), round(traffic / 1e6, 2), round(traffic / (avg_us * 1e-6) / 1e9) if avg_us else ""])
+                     round(f["mops"] / n), round(traffic / 1e6, 2), round(traffic / (avg_us * 1e-6) / 1e9) if avg_us else "",
+                     # effective shader clock while the family's kernels ran: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md,
+                     # DVFS give-back); reads high for dispatches much shorter than 0.3 ms
+                     round(f["gui"] / 8.0 / f["ns"], 2) if f["ns"] and f["gui"] else ""])
     with open(os.path.join(out_dir, f"{tag}_kernel_family_counters.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel_family", "launches", "avg_us", "pct_of_kernel_time", "mfma_util_pct", "mfma_mops_per_launch",
-                    "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s"])
+                    "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s", "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)"])
         w.writerows(rows)
     # per LAYER rows for the row-block gathers: one row per (kernel instance, grid), i.e. per layer shape -- the family average above mixes
     # 0.4 ms layers with 15 us ones
