@@ -307,7 +307,7 @@ struct RowsPlan {
     int XR, XRT;                        // x rows per image of a tile (tile rows + halo), per tile
     int rowb, cpitch;                   // LDS bytes per x row / x channel
     int halo, NBY, drowb, dpitch;       // dy: halo blocks loaded (image rows wider than the tile); blocks loaded per row; LDS bytes per row / channel
-    int plane_bytes, smem_bytes;        // one operand plane = x part + dy part
+    int plane_bytes, smem_bytes, pc;    // one operand plane = x part + dy part; pc: producer / consumer waves on two buffers
     int nxbl, nxitems, nyitems;         // log2 of the 8-pixel blocks per x row; staging items per tile
     int bj, jtiles, nchunks, ngroups, psplit, tiles_per_split;
     int NPH, NT, Kp;                    // K' layout of the result slabs: as PatchPlan / PatchWgrad

@@ -57,8 +57,14 @@ __device__ __forceinline__ void to_planes(const u32x4 (&raw)[S16 ? 1 : 2], float
     }
 }
 
-template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NIY>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
+// PC (one-plane modes, two LDS buffers): 8 waves, PRODUCER / CONSUMER split.  Waves 0-3 only read fragments and issue MFMAs; waves 4-7 only
+// move the next tile (global loads, conversion, LDS writes) into the other buffer; one barrier per tile.  With all of it in the same 4
+// waves (one per SIMD: 270-320 registers) the matrix core idled while a wave sat in the load issue (64 KB per tile through the texture
+// path: ~1600 of 5800 cycles per tile by clock64), in the conversion + LDS writes (~1200) and at the second barrier -- 37 % of a tile's
+// time was its k loop; interleaving the staging work INTO the k loop of the same waves did not help either (a wave blocked on a full
+// vector-memory queue issues no MFMA).
+template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NIY, bool PC>
+__global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
                                                                  const Geom g, const RowsPlan rp, const float* __restrict__ x_scale,
                                                                  const float* __restrict__ dy_scale) {
     constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3 (x_scale / dy_scale: amax slots)
@@ -82,7 +88,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wj = wave % NWJ, part = wave / NWJ;    // GK 2: kernel rows 2 * part, 2 * part + 1;  CI2: chunk 2 * chunk2 + part
+    const bool producer = PC && wave >= 4;
+    const int stid = tid & 255;                      // staging-item index of this thread (PC: of the producer threads)
+    const int wj = (wave & 3) % NWJ, part = (wave & 3) / NWJ;    // GK 2: kernel rows 2 * part, 2 * part + 1;  CI2: chunk 2 * chunk2 + part
     const int l31 = lane & 31, lh = lane >> 5;
     int jt, chunk, split;
     {
@@ -98,8 +106,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * YE);
     const int tile_beg = split * rp.tiles_per_split, tile_end = min(rp.mtiles, tile_beg + rp.tiles_per_split);
     const int rowb = rp.rowb, cpitch = rp.cpitch, drowb = rp.drowb, dpitch = rp.dpitch, plane_bytes = rp.plane_bytes;
-    unsigned char* const xs = lds;                                // [plane][NCI channels][cpitch]
-    unsigned char* const ys = lds + NCI * cpitch;                 // [plane][BJ channels][dpitch]   (a plane = x part + dy part)
+    // LDS: [buffer (PC: 2)][plane][x part: NCI channels x cpitch | dy part: BJ channels x dpitch]
+    static_assert(!PC || NPL == 1, "the producer / consumer split is the one-plane modes'");
+    const int buf_bytes = NPL * plane_bytes;
 
     struct Tile { int b0, y0, x0; bool ok; };
     auto tile_of = [&](int mt) {
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
     unsigned xi_lds[NIX];
 #pragma unroll
     for (int i = 0; i < NIX; ++i) {
-        const int e = tid + i * 256;
+        const int e = stid + i * 256;
         const int xb = e & ((1 << rp.nxbl) - 1), t1 = e >> rp.nxbl;
         const int ci = rp.dXRT.div(t1), rowi = t1 - ci * rp.XRT;
         const int tb = rp.dXR.div(rowi), j = rowi - tb * rp.XR;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
     unsigned yi_lds[NIY];
 #pragma unroll
     for (int i = 0; i < NIY; ++i) {
-        const int e = tid + i * 256;
+        const int e = stid + i * 256;
         const int t1 = rp.dNBY.div(e), blk = e - t1 * rp.NBY - rp.halo;      // -1 .. TW/8 with the halo, else 0 .. TW/8 - 1
         const int nn = t1 >> (thl + rp.tbl), rowi = t1 & ((1 << (thl + rp.tbl)) - 1);
         const bool ok = (e < rp.nyitems) & (j0 + nn < g.Cout);
@@ -156,15 +165,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
             if constexpr (!Y16) yr[i][1] = buf_load_u4s(rdy, ok ? (e0 + 4u) * YE : kOOB, 0);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
-            if (tid + i * 256 >= rp.nxitems) continue;
+            if (stid + i * 256 >= rp.nxitems) continue;
             u32x4 pl[NPL];
             to_planes<ET, NPL, X16, SCALED>(xr[i], xsc, pl);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
-                unsigned char* d = xs + p * plane_bytes + xi_lds[i];
+                unsigned char* d = buf + p * plane_bytes + xi_lds[i];
                 if (IS == 1) {
                     *reinterpret_cast<u32x4*>(d) = pl[p];
                 } else {
@@ -177,11 +186,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
-            if (tid + i * 256 >= rp.nyitems) continue;
+            if (stid + i * 256 >= rp.nyitems) continue;
             u32x4 pl[NPL];
             to_planes<ET, NPL, Y16, SCALED>(yr[i], ysc, pl);
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(ys + p * plane_bytes + yi_lds[i]) = pl[p];
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(buf + NCI * cpitch + p * plane_bytes + yi_lds[i]) = pl[p];
         }
     };
 
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
     const unsigned blane = (unsigned)(((CI2 ? part * 32 : 0) + l31) * cpitch);
     const unsigned alane = (unsigned)((wj * 32 + l31) * dpitch);
     struct AF { u32x4 c; unsigned l, r; };
-    auto read_frags = [&](int kk, u32x4 (&bf)[NB][NPL], AF (&af)[NPL]) {
+    auto read_frags = [&](const unsigned char* buf, int kk, u32x4 (&bf)[NB][NPL], AF (&af)[NPL]) {
         const int q = 2 * kk + lh;
         const int bx = q & ((1 << bxl) - 1), trow = q >> bxl;                    // trow = tb * TH + ty
         const int ty = trow & ((1 << thl) - 1), tb = trow >> thl;
@@ -200,12 +209,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
             // GK 0: i = kernel row r.  GK 2: i = rr * 2 + column parity, kernel row r = 2 * part + rr
             const unsigned o = GK == 2 ? off + (unsigned)((2 * part + (i >> 1)) * rowb + (i & 1) * (rowb >> 1)) : off + (unsigned)(i * rowb);
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) bf[i][p] = *reinterpret_cast<const u32x4*>(xs + p * plane_bytes + o);
+            for (int p = 0; p < NPL; ++p) bf[i][p] = *reinterpret_cast<const u32x4*>(buf + p * plane_bytes + o);
         }
         const unsigned ao = alane + (unsigned)(trow * drowb + (bx + 1) * 16);
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
-            const unsigned char* a = ys + p * plane_bytes + ao;
+            const unsigned char* a = buf + NCI * cpitch + p * plane_bytes + ao;
             af[p].c = *reinterpret_cast<const u32x4*>(a);
             af[p].l = *reinterpret_cast<const unsigned*>(a - 4);                // positions -2, -1
             af[p].r = *reinterpret_cast<const unsigned*>(a + 16);               // positions 8, 9
@@ -218,65 +227,92 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const void* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // the k loop of one tile out of buffer `buf`
+    auto k_loop = [&](const unsigned char* buf) {
+        u32x4 bf[2][NB][NPL];
+        AF af[2][NPL];
+        read_frags(buf, 0, bf[0], af[0]);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            if (kk + 1 < NK) read_frags(buf, kk + 1, bf[(kk + 1) & 1], af[(kk + 1) & 1]);
+            // the three shifted dy fragments av[0] = dy[j-1 ..], av[1] = dy[j ..], av[2] = dy[j+1 ..]
+            u32x4 av[3][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const AF& a = af[kk & 1][p];
+                const unsigned d[6] = {a.l, a.c[0], a.c[1], a.c[2], a.c[3], a.r};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    av[0][p][k] = alignbit16(d[k + 1], d[k]);
+                    av[1][p][k] = d[k + 1];
+                    av[2][p][k] = alignbit16(d[k + 2], d[k + 1]);
+                }
+            }
+            const auto& b = bf[kk & 1];
+            if (GK == 0) {
+                // tap (r, s): dy shifted by 1 - s against the x positions
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma_split<ET, NPL>(av[2 - s], b[r], acc[r * 3 + s]);
+            } else {
+                // tap (rr, s): s = 0 -> (dy[j+1], odd), 1 -> (dy[j], even), 2 -> (dy[j], odd), 3 -> (dy[j-1], even)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    acc[rr * 4 + 0] = mfma_split<ET, NPL>(av[2], b[rr * 2 + 1], acc[rr * 4 + 0]);
+                    acc[rr * 4 + 1] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 0], acc[rr * 4 + 1]);
+                    acc[rr * 4 + 2] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 1], acc[rr * 4 + 2]);
+                    acc[rr * 4 + 3] = mfma_split<ET, NPL>(av[0], b[rr * 2 + 0], acc[rr * 4 + 3]);
+                }
+            }
+        }
+    };
+
     if (tile_beg < tile_end) {
-        Tile cur = tile_of(tile_beg);
-        load_tile(cur);
-        // the dy halo blocks are written only where the image row continues: zero the dy planes once
-        for (int o = tid * 16; o < NPL * plane_bytes; o += 256 * 16) {
+        // the dy halo blocks are written only where the image row continues: zero the dy parts once
+        for (int o = tid * 16; o < (PC ? 2 : 1) * buf_bytes; o += (PC ? 512 : 256) * 16) {
             const int r = o % plane_bytes;
             if (r >= NCI * cpitch) *reinterpret_cast<u32x4*>(lds + o) = u32x4{0u, 0u, 0u, 0u};
         }
-        lds_barrier();
-        store_tile();
-        lds_barrier();
-        for (int mt = tile_beg; mt < tile_end; ++mt) {
-            const Tile nxt = tile_of(mt + 1);
-            load_tile(nxt);                              // (past the last tile: all-zero range, nothing is fetched)
-            u32x4 bf[2][NB][NPL];
-            AF af[2][NPL];
-            read_frags(0, bf[0], af[0]);
-#pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
-                if (kk + 1 < NK) read_frags(kk + 1, bf[(kk + 1) & 1], af[(kk + 1) & 1]);
-                // the three shifted dy fragments av[0] = dy[j-1 ..], av[1] = dy[j ..], av[2] = dy[j+1 ..]
-                u32x4 av[3][NPL];
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    const AF& a = af[kk & 1][p];
-                    const unsigned d[6] = {a.l, a.c[0], a.c[1], a.c[2], a.c[3], a.r};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        av[0][p][k] = alignbit16(d[k + 1], d[k]);
-                        av[1][p][k] = d[k + 1];
-                        av[2][p][k] = alignbit16(d[k + 2], d[k + 1]);
-                    }
+        if (PC) {
+            // two separate loops with the same barrier count: nothing of one role is live in the other (accumulators / staging registers)
+            if (producer) {
+                load_tile(tile_of(tile_beg));
+                lds_barrier();
+                store_tile(lds);
+                load_tile(tile_of(tile_beg + 1));
+                lds_barrier();
+                for (int mt = tile_beg; mt < tile_end; ++mt) {
+                    const int par = (mt - tile_beg) & 1;
+                    store_tile(lds + (par ^ 1) * buf_bytes);       // tile mt + 1, loaded one iteration ago
+                    load_tile(tile_of(mt + 2));                    // (past the last tile: all-zero range, nothing is fetched)
+                    lds_barrier();
                 }
-                const auto& b = bf[kk & 1];
-                if (GK == 0) {
-                    // tap (r, s): dy shifted by 1 - s against the x positions
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma_split<ET, NPL>(av[2 - s], b[r], acc[r * 3 + s]);
-                } else {
-                    // tap (rr, s): s = 0 -> (dy[j+1], odd), 1 -> (dy[j], even), 2 -> (dy[j], odd), 3 -> (dy[j-1], even)
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        acc[rr * 4 + 0] = mfma_split<ET, NPL>(av[2], b[rr * 2 + 1], acc[rr * 4 + 0]);
-                        acc[rr * 4 + 1] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 0], acc[rr * 4 + 1]);
-                        acc[rr * 4 + 2] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 1], acc[rr * 4 + 2]);
-                        acc[rr * 4 + 3] = mfma_split<ET, NPL>(av[0], b[rr * 2 + 0], acc[rr * 4 + 3]);
-                    }
-                }
+                return;
             }
-            lds_barrier();                               // every wave has read the tile
-            if (mt + 1 < tile_end) {
-                store_tile();
+            lds_barrier();
+            lds_barrier();
+            for (int mt = tile_beg; mt < tile_end; ++mt) {
+                k_loop(lds + ((mt - tile_beg) & 1) * buf_bytes);
                 lds_barrier();
             }
-            cur = nxt;
+        } else {
+            load_tile(tile_of(tile_beg));
+            lds_barrier();
+            store_tile(lds);
+            lds_barrier();
+            for (int mt = tile_beg; mt < tile_end; ++mt) {
+                load_tile(tile_of(mt + 1));              // (past the last tile: all-zero range, nothing is fetched)
+                k_loop(lds);
+                lds_barrier();                           // every wave has read the tile
+                if (mt + 1 < tile_end) {
+                    store_tile(lds);
+                    lds_barrier();
+                }
+            }
         }
     }
+    if (producer) return;
 
     // ---- D[cout][channel of the chunk] per tap -> dst[split][cout][kprime], kprime = ((chunk * NPH + ph) * NT + tap) * 32 + ci ----
     float* o = dst + (size_t)split * rp.slab;
@@ -311,10 +347,19 @@ void launch_rows(const void* x, const void* dy, float* part, const Geom& g, cons
     constexpr int NIX = GK == 2 ? 10 : (CI2 ? 8 : 4);
     constexpr int NIY = GK == 2 ? 6 : (CI2 ? 5 : 10);
     dim3 grid(p.jtiles, p.ngroups, p.psplit);
-    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr_;
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY>), grid, dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p, xs, ys);
+#define AGAN_ROWS_LAUNCH(PC_)                                                                                                                         \
+    do {                                                                                                                                              \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_>), \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
+        (void)attr_;                                                                                                                                  \
+        hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
+                           part, g, p, xs, ys);                                                                                                       \
+    } while (0)
+    if constexpr (NPL == 1) {
+        if (p.pc) { AGAN_ROWS_LAUNCH(true); return; }
+    }
+    AGAN_ROWS_LAUNCH(false);
+#undef AGAN_ROWS_LAUNCH
 }
 template <int ET, int NPL, bool X16, bool Y16>
 void launch_rows_gk(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
@@ -363,17 +408,20 @@ RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16) {
     p.XR = IS * (TH - 1) + R;
     p.XRT = TB * p.XR;
     p.rowb = IS * TW * 2;
-    // channel pitches = 16 mod 256: the 8 lanes of a ds_read_b128 cycle hit 8 different 16-byte bank groups
-    p.cpitch = (p.XRT * p.rowb + 255) / 256 * 256 + 16;
+    // channel pitches = odd multiples of 16 bytes: the 8 lanes of a ds_read_b128 cycle hit 8 different 16-byte bank groups
+    auto odd16 = [](int bytes) { const int q = (bytes + 15) / 16; return ((q & 1) ? q : q + 1) * 16; };
+    p.cpitch = odd16(p.XRT * p.rowb + 16);
     p.halo = p.tiles_x > 1 ? 1 : 0;
     // a dy row = [left halo block][TW / 8 blocks][right halo block]; rows that never load a halo share it: the right neighbour of a row's last
     // block is the (always zero) left halo slot of the next row, the last row's is the channel's 16-byte pad
     p.drowb = (TW / 8 + 1 + p.halo) * 16;
-    p.dpitch = (TB * TH * p.drowb + 255) / 256 * 256 + 16;
+    p.dpitch = odd16(TB * TH * p.drowb + 16);
     p.bj = (p.gk == 2 || p.ci2) ? 64 : 128;
     const int nci = p.ci2 ? 64 : 32;
     p.plane_bytes = nci * p.cpitch + p.bj * p.dpitch;
-    p.smem_bytes = planes * p.plane_bytes;
+    static const bool nopc = getenv("AGAN_WG_ROWS_NOPC") != nullptr;
+    p.pc = (!nopc && planes == 1 && 2 * p.plane_bytes <= 160 * 1024) ? 1 : 0;      // producer / consumer waves on two LDS buffers
+    p.smem_bytes = (p.pc ? 2 : 1) * planes * p.plane_bytes;
     if (p.smem_bytes > 160 * 1024) return p;
     p.nxbl = pow2ceil_log_w(IS * TW / 8);
     p.nxitems = nci * p.XRT << p.nxbl;
@@ -385,7 +433,10 @@ RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16) {
     p.ngroups = cdiv(g.Cin, nci);
     const int wgs = p.jtiles * p.ngroups;
     int ps = 1;
-    if (wgs < 512) ps = std::max(1, std::min(512 / wgs, p.mtiles));       // one workgroup per CU is resident: cover the chip about twice
+    // one workgroup per CU is resident: split the pixel tiles until the grid is ONE round of the 256 CUs (measured sweep, round 3: 256 slots
+    // 86-96 us per layer, 512: 99-131, 1024: 126-154 -- every further split writes and re-reads one more [cout][K'] slab)
+    static const int slots = getenv("AGAN_WG_ROWS_SLOTS") ? atoi(getenv("AGAN_WG_ROWS_SLOTS")) : 256;
+    if (wgs < slots) ps = std::max(1, std::min(slots / wgs, p.mtiles));
     p.tiles_per_split = cdiv(p.mtiles, ps);
     p.psplit = cdiv(p.mtiles, p.tiles_per_split);
     p.NPH = IS == 2 ? 4 : 1;
