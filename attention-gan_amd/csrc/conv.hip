@@ -881,13 +881,14 @@ int agan_conv_effective_prec(const agan_conv_geom* g, int prec) {
 int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int prec) {
     if (prec == AGAN_PREC_F32 || check_geom(g) || prec_planes(prec) == 0) return AGAN_PREC_F32;
     if (!patch_supported(make_geom(g))) return AGAN_PREC_F32;
-    if (pack_mode == AGAN_PACK_UP_FWD) return AGAN_PREC_F32;
 #ifndef AGAN_BF16X6_PATCH_WGRAD
     if (prec == AGAN_PREC_BF16X6) {
         static const bool f32wg = getenv("AGAN_BF16X6_WGRAD_F32") != nullptr;
-        return f32wg ? AGAN_PREC_F32 : AGAN_PREC_F16X3;
+        prec = f32wg ? AGAN_PREC_F32 : AGAN_PREC_F16X3;
     }
 #endif
+    // (round 3: the row-resident kernel takes the upsample conv as the conv3x3 on the upsampled image it is -- conv_wgrows.hip)
+    if (pack_mode == AGAN_PACK_UP_FWD && (prec == AGAN_PREC_F32 || !plan_rows_wgrad(make_geom(g), prec, false, false, true).ok)) return AGAN_PREC_F32;
     return prec;
 }
 
@@ -1071,8 +1072,10 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
     if (patch_supported(gg)) {
         const PatchPlan pp = make_patch_plan(gg);
         a = std::max({a, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16).ws_bytes, plan_patch_wgrad(gg, pp, AGAN_PREC_BF16X6).ws_bytes});
-        const RowsPlan rp = plan_rows_wgrad(gg, AGAN_PREC_BF16, false, false);       // (the plan's split does not depend on planes / storage; one plane: the most geometries)
-        if (rp.ok) a = std::max(a, rp.ws_bytes);
+        for (int up = 0; up < 2; ++up) {     // (the plan's split does not depend on planes / storage; one plane: the most geometries)
+            const RowsPlan rp = plan_rows_wgrad(gg, AGAN_PREC_BF16, false, false, up != 0);
+            if (rp.ok) a = std::max(a, rp.ws_bytes);
+        }
     }
     return a;
 }
@@ -1120,9 +1123,9 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
     hipStream_t st = as_stream(stream);
-    if (prec != AGAN_PREC_F32 && !up) {
+    if (prec != AGAN_PREC_F32) {
         // the row-resident kernel (conv_wgrows.hip) where it takes the geometry: same slab format, its own pixel split
-        const RowsPlan rp = plan_rows_wgrad(g, prec, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
+        const RowsPlan rp = plan_rows_wgrad(g, prec, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32, up);
         if (rp.ok) {
             if (rp.ws_bytes > ws_bytes || !ws) {
                 set_error("conv_wgrad: workspace %zu < %zu", ws_bytes, rp.ws_bytes);
@@ -1141,7 +1144,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
                                    rp.slab, (const float*)nullptr, 1, 1, reduced, 0);
                 if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
             }
-            launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, false, rp.NPH, rp.NT, rp.Kp, accumulate, st);
+            launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, false, rp.NPH, rp.NT, rp.Kp, accumulate, st);      // (ups: a plain 3x3 result)
             return check_launch("conv_wgrad/unpack");
         }
     }

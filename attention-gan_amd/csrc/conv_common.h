@@ -301,7 +301,7 @@ void launch_p16_gather(const void* in, const void* wk, const float* bias, void* 
                        const void* lrelu_mask, hipStream_t st, bool in16, bool out16);
 // ---- row-resident weight gradient (conv_wgrows.hip): conv3x3 s1 / conv4x4 s2, one- and two-plane modes, fp32 or 16-bit storage ------
 struct RowsPlan {
-    int ok, gk, ci2;                    // gk 0: conv3x3 stride 1 (ci2: two 32-channel chunks per workgroup, 64 output channels), 2: conv4x4 stride 2
+    int ok, gk, ci2, ups;               // ups: the upsample conv, as conv3x3 on the upsampled image built in LDS;  gk 0: conv3x3 stride 1 (ci2: two 32-channel chunks per workgroup, 64 output channels), 2: conv4x4 stride 2
     int twl, thl, tbl;                  // log2 of the tile's columns (x positions), dy rows, images: 128 pixels
     int tiles_x, tiles_y, tiles_b, mtiles;
     int XR, XRT;                        // x rows per image of a tile (tile rows + halo), per tile
@@ -315,7 +315,7 @@ struct RowsPlan {
     FastDiv dXRT, dXR, dNBY;
 };
 int prec_planes(int prec);
-RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16);
+RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16, bool up = false);
 void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, int prec, hipStream_t st,
                        const float* x_scale, const float* dy_scale, bool x16, bool y16);
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, int NPH, int NT, int Kp, int accumulate,

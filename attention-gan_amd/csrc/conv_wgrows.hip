@@ -63,13 +63,14 @@ __device__ __forceinline__ void to_planes(const u32x4 (&raw)[S16 ? 1 : 2], float
 // path: ~1600 of 5800 cycles per tile by clock64), in the conversion + LDS writes (~1200) and at the second barrier -- 37 % of a tile's
 // time was its k loop; interleaving the staging work INTO the k loop of the same waves did not help either (a wave blocked on a full
 // vector-memory queue issues no MFMA).
-template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NIY, bool PC>
+template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NIY, bool PC, bool UPS>
 __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
                                                                  const Geom g, const RowsPlan rp, const float* __restrict__ x_scale,
                                                                  const float* __restrict__ dy_scale) {
     constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3 (x_scale / dy_scale: amax slots)
     static_assert(!(X16 || Y16) || NPL == 1, "16-bit activation storage goes with the one-plane modes");
     static_assert(!CI2 || GK == 0, "the two-chunk layout is the 3x3 kernel's");
+    static_assert(!UPS || GK == 0, "the upsample conv is a 3x3 conv on the upsampled image");
     float xsc = 1.f, ysc = 1.f, unscale = 1.f;
     if (SCALED) {
         float ix, iy;
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
     const int twl = rp.twl, thl = rp.thl, bxl = twl - 3;
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     constexpr unsigned XE = X16 ? 2u : 4u, YE = Y16 ? 2u : 4u;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * XE);
+    // UPS: x is the LOW-RES tensor (IH/2 x IW/2); g describes the conv on its nearest-neighbour upsampling, which is built on the way into LDS
+    const int sw = UPS ? g.IW >> 1 : g.IW, shw = UPS ? ihw >> 2 : ihw;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * shw * XE);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (size_t)g.B * g.Cout * ohw * YE);
     const int tile_beg = split * rp.tiles_per_split, tile_end = min(rp.mtiles, tile_beg + rp.tiles_per_split);
     const int rowb = rp.rowb, cpitch = rp.cpitch, drowb = rp.drowb, dpitch = rp.dpitch, plane_bytes = rp.plane_bytes;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         const int ci = rp.dXRT.div(t1), rowi = t1 - ci * rp.XRT;
         const int tb = rp.dXR.div(rowi), j = rowi - tb * rp.XR;
         const bool ok = (e < rp.nxitems) & (c0 + ci < g.Cin);
-        xi_goff[i] = ok ? (c0 + ci) * ihw : -1;
+        xi_goff[i] = ok ? (c0 + ci) * shw : -1;
         xi_tb[i] = tb; xi_j[i] = j; xi_xb[i] = xb;
         xi_lds[i] = (unsigned)(ci * cpitch + rowi * rowb + xb * (IS == 2 ? 8 : 16));
     }
@@ -146,15 +149,26 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         yi_row[i] = rowi; yi_blk[i] = blk;
         yi_lds[i] = (unsigned)(nn * dpitch + rowi * drowb + (blk + 1) * 16);
     }
-    u32x4 xr[NIX][X16 ? 1 : 2], yr[NIY][Y16 ? 1 : 2];
+    u32x4 xr[NIX][(X16 || UPS) ? 1 : 2], yr[NIY][Y16 ? 1 : 2];
     auto load_tile = [&](const Tile& t) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int b = t.b0 + xi_tb[i], iy = IS * t.y0 + xi_j[i] - 1, ix = IS * t.x0 + 8 * xi_xb[i];
             const bool ok = t.ok & (xi_goff[i] >= 0) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & (ix < g.IW);
-            const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * ihw + iy * g.IW + ix);
-            xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
-            if constexpr (!X16) xr[i][1] = buf_load_u4s(rx, ok ? (e0 + 4u) * XE : kOOB, 0);
+            if constexpr (UPS) {
+                // 8 upsampled pixels = 4 source pixels of source row iy / 2
+                const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * shw + (iy >> 1) * sw + (ix >> 1));
+                if constexpr (X16) {
+                    const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, ok ? e0 * XE : kOOB, 0, 0));
+                    xr[i][0] = u32x4{v.x, v.y, 0u, 0u};
+                } else {
+                    xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
+                }
+            } else {
+                const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * ihw + iy * g.IW + ix);
+                xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
+                if constexpr (!X16) xr[i][1] = buf_load_u4s(rx, ok ? (e0 + 4u) * XE : kOOB, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
@@ -170,7 +184,25 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         for (int i = 0; i < NIX; ++i) {
             if (stid + i * 256 >= rp.nxitems) continue;
             u32x4 pl[NPL];
-            to_planes<ET, NPL, X16, SCALED>(xr[i], xsc, pl);
+            if constexpr (UPS) {
+                // every source pixel twice
+                if constexpr (X16) {
+                    pl[0] = u32x4{__builtin_amdgcn_perm(xr[i][0][0], xr[i][0][0], 0x01000100u), __builtin_amdgcn_perm(xr[i][0][0], xr[i][0][0], 0x03020302u),
+                                  __builtin_amdgcn_perm(xr[i][0][1], xr[i][0][1], 0x01000100u), __builtin_amdgcn_perm(xr[i][0][1], xr[i][0][1], 0x03020302u)};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        unsigned e[NPL];
+                        const float a = __uint_as_float(xr[i][0][k]);
+                        if (SCALED) split_pack2<ET, NPL>(a * xsc, a * xsc, e);
+                        else split_pack2<ET, NPL>(a, a, e);
+#pragma unroll
+                        for (int p = 0; p < NPL; ++p) pl[p][k] = e[p];
+                    }
+                }
+            } else {
+                to_planes<ET, NPL, X16, SCALED>(xr[i], xsc, pl);
+            }
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
                 unsigned char* d = buf + p * plane_bytes + xi_lds[i];
@@ -342,17 +374,17 @@ int pow2ceil_log_w(int v) {
     return l;
 }
 
-template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16>
+template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, bool UPS>
 void launch_rows(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
     constexpr int NIX = GK == 2 ? 10 : (CI2 ? 8 : 4);
     constexpr int NIY = GK == 2 ? 6 : (CI2 ? 5 : 10);
     dim3 grid(p.jtiles, p.ngroups, p.psplit);
 #define AGAN_ROWS_LAUNCH(PC_)                                                                                                                         \
     do {                                                                                                                                              \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_>), \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
         (void)attr_;                                                                                                                                  \
-        hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
+        hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
                            part, g, p, xs, ys);                                                                                                       \
     } while (0)
     if constexpr (NPL == 1) {
@@ -363,9 +395,14 @@ void launch_rows(const void* x, const void* dy, float* part, const Geom& g, cons
 }
 template <int ET, int NPL, bool X16, bool Y16>
 void launch_rows_gk(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
-    if (p.gk == 2) launch_rows<ET, NPL, 2, false, X16, Y16>(x, dy, part, g, p, st, xs, ys);
-    else if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16>(x, dy, part, g, p, st, xs, ys);
-    else launch_rows<ET, NPL, 0, false, X16, Y16>(x, dy, part, g, p, st, xs, ys);
+    if (p.gk == 2) launch_rows<ET, NPL, 2, false, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
+    else if (p.ups) {
+        if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
+        else launch_rows<ET, NPL, 0, false, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
+    } else {
+        if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
+        else launch_rows<ET, NPL, 0, false, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
+    }
 }
 template <int ET>
 void launch_rows_dt(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, bool x16, bool y16) {
@@ -381,9 +418,27 @@ namespace agan {
 namespace conv {
 
 // Plan of the row-resident weight gradient for FORWARD geometry g in mode prec (p.ok == 0: the kernel does not take the call).
-RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16) {
+// the geometry the kernel works on: the forward geometry itself, or -- for the folded upsample conv (4 classes of 2x2 taps on the low-res
+// input) -- the plain conv3x3 on the upsampled image that it is a refactoring of: 9 taps per output pixel instead of the folded 4, on the
+// 16-bit matrix core instead of the fp32 one, and the result is the 3x3 OIHW gradient directly (no class unfolding)
+Geom rows_geom(const Geom& g, bool up) {
+    if (!up) return g;
+    Geom u = g;
+    u.IH = g.OH; u.IW = g.OW;
+    u.R = u.S = 3; u.RS = 9; u.K = g.Cin * 9;
+    u.OS = 1; u.SY = 1; u.DY = 1; u.OY0 = u.OY1 = -1;
+    u.OHs = g.OH; u.OWs = g.OW; u.HWs = g.OH * g.OW; u.Mtot = g.B * u.HWs;
+    u.dHWs = make_fastdiv((unsigned)u.HWs); u.dOWs = make_fastdiv((unsigned)u.OWs);
+    return u;
+}
+
+RowsPlan plan_rows_wgrad(const Geom& gf, int prec, bool x16, bool y16, bool up) {
     RowsPlan p;
     memset(&p, 0, sizeof(p));
+    static const bool noup = getenv("AGAN_WG_ROWS_NOUP") != nullptr;
+    if (up && (noup || gf.R != 2 || gf.S != 2 || gf.OS != 2 || gf.OH != 2 * gf.IH || gf.OW != 2 * gf.IW)) return p;
+    const Geom g = rows_geom(gf, up);
+    p.ups = up ? 1 : 0;
     static const bool off = getenv("AGAN_WG_ROWS_OFF") != nullptr;
     if (off) return p;
     const int planes = prec_planes(prec);
@@ -451,8 +506,9 @@ RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16) {
     return p;
 }
 
-void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, int prec, hipStream_t st,
+void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& gf, const RowsPlan& p, int prec, hipStream_t st,
                        const float* x_scale, const float* dy_scale, bool x16, bool y16) {
+    const Geom g = rows_geom(gf, p.ups != 0);
     switch (prec) {
         case AGAN_PREC_BF16: launch_rows_dt<0>(x, dy, part, g, p, st, x16, y16); break;
         case AGAN_PREC_F16: launch_rows_dt<1>(x, dy, part, g, p, st, x16, y16); break;
