@@ -1132,20 +1132,25 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
                 return AGAN_EWORKSPACE;
             }
             float* wsf = static_cast<float*>(ws);
-            float* reduced = rp.psplit > 1 ? wsf + rp.slab * rp.psplit : wsf;
             AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
             timer_begin(st);
             launch_rows_wgrad(x_v, dy_v, wsf, g, rp, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
             timer_end(st);
             if (int e = check_launch("conv_wgrad/rows")) return e;
-            if (rp.psplit > 1) {
+            // few slabs: summed inside the unpack pass; many (the small layers, split 100-fold over their pixels): the bandwidth-bound slab sum first
+            const float* src = wsf;
+            int nsl = rp.psplit;
+            if (rp.psplit > 4) {
+                float* reduced = wsf + rp.slab * rp.psplit;
                 const size_t n = (size_t)g.Cout * rp.Kp;
                 hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, rp.psplit, n,
                                    rp.slab, (const float*)nullptr, 1, 1, reduced, 0);
                 if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
+                src = reduced;
+                nsl = 1;
             }
-            launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, false, rp.NPH, rp.NT, rp.Kp, accumulate, st);      // (ups: a plain 3x3 result)
-            return check_launch("conv_wgrad/unpack");
+            launch_wgrad_sum_unpack(src, nsl, rp.slab, dw, g.Cout, g.Cin, kh, kw, rp.NPH, rp.NT, rp.Kp, accumulate, st);      // (ups: a plain 3x3 result)
+            return check_launch("conv_wgrad/sum_unpack");
         }
     }
     if (prec != AGAN_PREC_F32) {
@@ -1162,13 +1167,18 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
         launch_patch_wgrad(x_v, dy_v, wsf, g, pp, p, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
         timer_end(st);
         if (int e = check_launch("conv_wgrad/patch")) return e;
+        if (!up && p.psplit <= 4) {
+            launch_wgrad_sum_unpack(wsf, p.psplit, p.slab, dw, g.Cout, g.Cin, kh, kw, pp.NPH, pp.NT, p.Kp, accumulate, st);
+            return check_launch("conv_wgrad/sum_unpack");
+        }
         if (p.psplit > 1) {
             const size_t n = (size_t)p.ncls * g.Cout * p.Kp;
             hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, p.psplit, n,
                                p.slab, (const float*)nullptr, 1, 1, reduced, 0);
             if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
         }
-        launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, up, pp, p, accumulate, st);
+        if (!up) launch_wgrad_sum_unpack(reduced, 1, p.slab, dw, g.Cout, g.Cin, kh, kw, pp.NPH, pp.NT, p.Kp, accumulate, st);
+        else launch_patch_wgrad_unpack(reduced, dw, g.Cout, g.Cin, kh, kw, up, pp, p, accumulate, st);
         return check_launch("conv_wgrad/unpack");
     }
     if (prec == AGAN_PREC_F32 && !up && small_n_wgrad_supported(g)) {

@@ -320,6 +320,9 @@ void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g
                        const float* x_scale, const float* dy_scale, bool x16, bool y16);
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, int NPH, int NT, int Kp, int accumulate,
                                hipStream_t st);
+// direct convs: sum of the pixel-split slabs + OIHW unpack in one coalesced pass (kh * kw <= 16)
+void launch_wgrad_sum_unpack(const float* slabs, int nslabs, size_t slab, float* dw, int cout, int cin, int kh, int kw, int NPH, int NT, int Kp,
+                             int accumulate, hipStream_t st);
 PatchWgrad plan_patch_wgrad(const Geom& g, const PatchPlan& pp, int prec);
 void launch_patch_wgrad(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, int prec,
                         hipStream_t st, const float* x_scale = nullptr, const float* dy_scale = nullptr, bool x16 = false, bool y16 = false);

@@ -820,6 +820,50 @@ __global__ __launch_bounds__(256) void unpack_patch_wgrad_kernel(const float* __
     }
 }
 
+// The same for the direct (non-folded) convs, FUSED with the sum over the pixel-split slabs and coalesced on both sides: a wave owns one
+// (output channel, 32-channel chunk) tile, reads its kh*kw tap rows (32 consecutive floats each, from every slab) into LDS and writes the
+// 32 * kh*kw floats of dw[co][chunk*32 ..][..][..], which are contiguous in OIHW.  (The element-wise kernel above reads with a 128-byte
+// stride between lanes -- 1 of 16 fetched floats used -- and ran behind a separate slab-sum launch: together ~20 us of launch-bound
+// work per layer, 10 % of the 16-bit-storage step in the round-3 profile.)
+__global__ __launch_bounds__(256) void sum_unpack_wgrad_kernel(const float* __restrict__ slabs, int nslabs, size_t slab, float* __restrict__ dw,
+                                                               int cout, int cin, int kh, int kw, int NPH, int NT, int Kp, int accumulate) {
+    __shared__ float tile[4][16 * 33];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int kk = kh * kw, nchunks = (cin + kCH - 1) / kCH;
+    const int ntiles = cout * nchunks;
+    for (int t0 = blockIdx.x * 4; t0 < ntiles; t0 += gridDim.x * 4) {
+        const int tl = t0 + w;
+        if (tl < ntiles) {                                       // (wave-uniform)
+            const int co = tl / nchunks, chunk = tl - co * nchunks;
+            const float* base = slabs + (size_t)co * Kp;
+            for (int t = half; t < kk; t += 2) {
+                const int r = t / kw, s = t - r * kw;
+                int ph = 0, tap = t;
+                if (NPH != 1) { ph = (r & 1) * 2 + (s & 1); tap = (r >> 1) * (kw / 2) + (s >> 1); }
+                const float* p = base + ((chunk * NPH + ph) * NT + tap) * kCH + l31;
+                float v = p[0];
+                if (nslabs > 1) {                              // (<= 4: the caller sums larger splits with the slab-sum kernel first)
+                    const float v1 = p[slab], v2 = nslabs > 2 ? p[2 * slab] : 0.f, v3 = nslabs > 3 ? p[3 * slab] : 0.f;
+                    v = (v + v1) + (v2 + v3);
+                }
+                tile[w][t * 33 + l31] = v;
+            }
+        }
+        __syncthreads();
+        if (tl < ntiles) {
+            const int co = tl / nchunks, chunk = tl - co * nchunks;
+            const int nci = min(kCH, cin - chunk * kCH);
+            float* o = dw + ((size_t)co * cin + chunk * kCH) * kk;
+            for (int j = lane; j < nci * kk; j += 64) {
+                const int ci = j / kk, t = j - ci * kk;
+                const float v = tile[w][t * 33 + ci];
+                o[j] = accumulate ? o[j] + v : v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ================================================================================================
 // weight packing: OIHW -> [class][k-step][plane][Nld][16] 16-bit; k-step = ((chunk * NPH + phase) * NT + tap) * 2 + half
 // ================================================================================================
@@ -1269,6 +1313,12 @@ void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, i
     const size_t total = (size_t)cout * cin * kh * kw;
     hipLaunchKernelGGL(unpack_patch_wgrad_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st, red, dw, cout, cin,
                        kh, kw, up ? 1 : 0, NPH, NT, Kp, accumulate);
+}
+void launch_wgrad_sum_unpack(const float* slabs, int nslabs, size_t slab, float* dw, int cout, int cin, int kh, int kw, int NPH, int NT, int Kp,
+                             int accumulate, hipStream_t st) {
+    const int ntiles = cout * cdiv(cin, kCH);
+    hipLaunchKernelGGL(sum_unpack_wgrad_kernel, dim3((unsigned)std::min(cdiv(ntiles, 4), 8192)), dim3(256), 0, st, slabs, nslabs, slab, dw, cout, cin, kh,
+                       kw, NPH, NT, Kp, accumulate);
 }
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,
                                int accumulate, hipStream_t st) {

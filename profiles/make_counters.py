@@ -36,6 +36,7 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_p16 2x2-class gather (D conv dgrad; upsample-conv fwd)", ["conv_p16_kernel<0, 1,", "conv_p16_kernel<1, 1,"]),
     ("conv_p16 3x3 gather (G ResBlock / D Block3x3 fwd + dgrad)", ["conv_p16_kernel<0, 0,", "conv_p16_kernel<1, 0,"]),
     ("conv_gather_patch16 (fwd/dgrad, 16-bit MFMA)", ["conv_patch_kernel"]),
+    ("conv_wgrad_rows (row-resident weight gradient, conv_wgrows.hip)", ["conv_wgrad_rows_kernel"]),
     ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
     ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
@@ -70,7 +71,7 @@ def bench_name(kernel, mode):
             return f"conv_gather_f32_n{n}"
     if "conv_wgrad_f32_kernel" in kernel:
         return "conv_wgrad_f32"
-    if "conv_patch_wgrad_kernel" in kernel:
+    if "conv_patch_wgrad_kernel" in kernel or "conv_wgrad_rows_kernel" in kernel:
         return f"conv_wgrad_{mode}"
     if "conv_patch_kernel" in kernel:
         for n in (128, 64, 32):
