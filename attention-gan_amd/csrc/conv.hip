@@ -1077,6 +1077,10 @@ size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g) {
             if (rp.ok) a = std::max(a, rp.ws_bytes);
         }
     }
+    {
+        const RowsPlan rp = plan_rows_wgrad(gg, AGAN_PREC_F32, false, false, false);
+        if (rp.ok) a = std::max(a, rp.ws_bytes);
+    }
     return a;
 }
 
@@ -1123,8 +1127,8 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
     if (!up) AGAN_REQUIRE(g.R == kh && g.S == kw && g.OS == 1, "conv_wgrad: geometry is not a direct %dx%d conv", kh, kw);
     else AGAN_REQUIRE(g.R == 2 && g.S == 2 && g.OS == 2 && kh == 3 && kw == 3, "conv_wgrad: geometry is not the folded upsample conv");
     hipStream_t st = as_stream(stream);
-    if (prec != AGAN_PREC_F32) {
-        // the row-resident kernel (conv_wgrows.hip) where it takes the geometry: same slab format, its own pixel split
+    if (!(prec == AGAN_PREC_F32 && small_n_wgrad_supported(g))) {
+        // the row-resident kernel (conv_wgrows.hip) where it takes the geometry (any mode, fp32 included): [cout][K'] slabs, its own pixel split
         const RowsPlan rp = plan_rows_wgrad(g, prec, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32, up);
         if (rp.ok) {
             if (rp.ws_bytes > ws_bytes || !ws) {

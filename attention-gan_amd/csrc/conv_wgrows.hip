@@ -67,8 +67,12 @@ template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, int NIX, int NI
 __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dy, float* __restrict__ dst,
                                                                  const Geom g, const RowsPlan rp, const float* __restrict__ x_scale,
                                                                  const float* __restrict__ dy_scale) {
+    // ET 2: fp32 operands on v_mfma_f32_32x32x2_f32 (AGAN_PREC_F32).  A 16-byte block is then 4 pixels, a k-group (8 pixels: 4 per lane half)
+    // is four MFMAs per tap with the block's registers as they are, and the column shifts are a choice of registers.
+    constexpr bool F32 = ET == 2;
     constexpr bool SCALED = (ET == 1 && NPL == 2);               // AGAN_PREC_F16X3 (x_scale / dy_scale: amax slots)
-    static_assert(!(X16 || Y16) || NPL == 1, "16-bit activation storage goes with the one-plane modes");
+    static_assert(!(X16 || Y16) || (NPL == 1 && !F32), "16-bit activation storage goes with the one-plane 16-bit modes");
+    static_assert(!F32 || (NPL == 1 && !PC && !UPS), "fp32 operands: one plane, one buffer, direct convs");
     static_assert(!CI2 || GK == 0, "the two-chunk layout is the 3x3 kernel's");
     static_assert(!UPS || GK == 0, "the upsample conv is a 3x3 conv on the upsampled image");
     float xsc = 1.f, ysc = 1.f, unscale = 1.f;
@@ -84,7 +88,9 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
     constexpr int NCI = CI2 ? 64 : 32;               // input channels per workgroup
     constexpr int NTW = GK == 2 ? 8 : 9;             // taps per wave
     constexpr int NB = GK == 2 ? 4 : 3;              // x fragments per k-step and wave
-    constexpr int NK = 8;                            // k-steps per tile (128 pixels)
+    constexpr int PXL = F32 ? 2 : 3;                 // log2 of the pixels per 16-byte LDS block
+    constexpr int PXB = 1 << PXL;
+    constexpr int NK = 128 / (2 * PXB);              // k-steps per tile (128 pixels; two blocks per k-step, one per lane half)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,9 +106,11 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         chunk = F % rp.ngroups; split = F / rp.ngroups;           // (CI2: a group is two chunks)
     }
     const int j0 = jt * BJ, c0 = chunk * NCI;
-    const int twl = rp.twl, thl = rp.thl, bxl = twl - 3;
+    const int twl = rp.twl, thl = rp.thl, bxl = twl - PXL;
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     constexpr unsigned XE = X16 ? 2u : 4u, YE = Y16 ? 2u : 4u;
+    // stored elements per staging item: one 16-byte LDS block = PXB operand values; from fp32 storage in a 16-bit mode that is two loads
+    constexpr int XRAW = (F32 || X16 || UPS) ? 1 : 2, YRAW = (F32 || Y16) ? 1 : 2;
     // UPS: x is the LOW-RES tensor (IH/2 x IW/2); g describes the conv on its nearest-neighbour upsampling, which is built on the way into LDS
     const int sw = UPS ? g.IW >> 1 : g.IW, shw = UPS ? ihw >> 2 : ihw;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * shw * XE);
@@ -122,42 +130,39 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         return t;
     };
 
-    // ---- staging items, tile independent parts.  x: (channel, tile x row, 16-byte block of 8 input pixels); dy: (channel, tile row,
-    //      block incl. the halo blocks when the image row continues beyond the tile); blocks fastest: a wave-load walks along rows ----
-    int xi_goff[NIX], xi_tb[NIX], xi_j[NIX], xi_xb[NIX];
-    unsigned xi_lds[NIX];
+    // ---- staging items, tile independent parts, ONE packed register each (decoded when used: a handful of VALU ops per item and tile).
+    //      x: (channel, tile x row, 16-byte block of PXB input pixels); dy: (channel, tile row, block incl. the halo blocks when the image row
+    //      continues beyond the tile); blocks fastest: a wave-load walks along rows.  A thread's x block index is the same for all its items
+    //      (the blocks per row are a power of two <= 256). ----
+    const int xi_xb = stid & ((1 << rp.nxbl) - 1);
+    int xi_pack[NIX];                 // ci << 16 | tb << 8 | row of the image's patch;  -1: no item
 #pragma unroll
     for (int i = 0; i < NIX; ++i) {
         const int e = stid + i * 256;
-        const int xb = e & ((1 << rp.nxbl) - 1), t1 = e >> rp.nxbl;
+        const int t1 = e >> rp.nxbl;
         const int ci = rp.dXRT.div(t1), rowi = t1 - ci * rp.XRT;
         const int tb = rp.dXR.div(rowi), j = rowi - tb * rp.XR;
-        const bool ok = (e < rp.nxitems) & (c0 + ci < g.Cin);
-        xi_goff[i] = ok ? (c0 + ci) * shw : -1;
-        xi_tb[i] = tb; xi_j[i] = j; xi_xb[i] = xb;
-        xi_lds[i] = (unsigned)(ci * cpitch + rowi * rowb + xb * (IS == 2 ? 8 : 16));
+        xi_pack[i] = ((e < rp.nxitems) & (c0 + ci < g.Cin)) ? (ci << 16 | tb << 8 | j) : -1;
     }
-    int yi_goff[NIY], yi_row[NIY], yi_blk[NIY];
-    unsigned yi_lds[NIY];
+    int yi_pack[NIY];                 // nn << 16 | tile row << 8 | block + 1;  -1: no item
 #pragma unroll
     for (int i = 0; i < NIY; ++i) {
         const int e = stid + i * 256;
-        const int t1 = rp.dNBY.div(e), blk = e - t1 * rp.NBY - rp.halo;      // -1 .. TW/8 with the halo, else 0 .. TW/8 - 1
+        const int t1 = rp.dNBY.div(e), blk = e - t1 * rp.NBY - rp.halo;      // -1 .. TW/PXB with the halo, else 0 .. TW/PXB - 1
         const int nn = t1 >> (thl + rp.tbl), rowi = t1 & ((1 << (thl + rp.tbl)) - 1);
-        const bool ok = (e < rp.nyitems) & (j0 + nn < g.Cout);
-        yi_goff[i] = ok ? (j0 + nn) * ohw : -1;
-        yi_row[i] = rowi; yi_blk[i] = blk;
-        yi_lds[i] = (unsigned)(nn * dpitch + rowi * drowb + (blk + 1) * 16);
+        yi_pack[i] = ((e < rp.nyitems) & (j0 + nn < g.Cout)) ? (nn << 16 | rowi << 8 | (blk + 1)) : -1;
     }
-    u32x4 xr[NIX][(X16 || UPS) ? 1 : 2], yr[NIY][Y16 ? 1 : 2];
+    u32x4 xr[NIX][XRAW], yr[NIY][YRAW];
     auto load_tile = [&](const Tile& t) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
-            const int b = t.b0 + xi_tb[i], iy = IS * t.y0 + xi_j[i] - 1, ix = IS * t.x0 + 8 * xi_xb[i];
-            const bool ok = t.ok & (xi_goff[i] >= 0) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & (ix < g.IW);
+            const int pk = xi_pack[i];
+            const int ci = pk >> 16, tb = (pk >> 8) & 255, j = pk & 255;
+            const int b = t.b0 + tb, iy = IS * t.y0 + j - 1, ix = IS * t.x0 + PXB * xi_xb;
+            const bool ok = t.ok & (pk >= 0) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & (ix < g.IW);
             if constexpr (UPS) {
                 // 8 upsampled pixels = 4 source pixels of source row iy / 2
-                const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * shw + (iy >> 1) * sw + (ix >> 1));
+                const unsigned e0 = (unsigned)((b * g.Cin + c0 + ci) * shw + (iy >> 1) * sw + (ix >> 1));
                 if constexpr (X16) {
                     const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, ok ? e0 * XE : kOOB, 0, 0));
                     xr[i][0] = u32x4{v.x, v.y, 0u, 0u};
@@ -165,26 +170,33 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
                     xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
                 }
             } else {
-                const unsigned e0 = (unsigned)(xi_goff[i] + b * g.Cin * ihw + iy * g.IW + ix);
+                const unsigned e0 = (unsigned)((b * g.Cin + c0 + ci) * ihw + iy * g.IW + ix);
                 xr[i][0] = buf_load_u4s(rx, ok ? e0 * XE : kOOB, 0);
-                if constexpr (!X16) xr[i][1] = buf_load_u4s(rx, ok ? (e0 + 4u) * XE : kOOB, 0);
+                if constexpr (XRAW == 2) xr[i][1] = buf_load_u4s(rx, ok ? (e0 + 4u) * XE : kOOB, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
-            const int b = t.b0 + (yi_row[i] >> thl), oy = t.y0 + (yi_row[i] & ((1 << thl) - 1)), ox = t.x0 + 8 * yi_blk[i];
-            const bool ok = t.ok & (yi_goff[i] >= 0) & (b < g.B) & (oy < g.OH) & ((unsigned)ox < (unsigned)g.OW);
-            const unsigned e0 = (unsigned)(yi_goff[i] + b * g.Cout * ohw + oy * g.OW + ox);
+            const int pk = yi_pack[i];
+            const int nn = pk >> 16, rowi = (pk >> 8) & 255, blk = (pk & 255) - 1;
+            const int b = t.b0 + (rowi >> thl), oy = t.y0 + (rowi & ((1 << thl) - 1)), ox = t.x0 + PXB * blk;
+            const bool ok = t.ok & (pk >= 0) & (b < g.B) & (oy < g.OH) & ((unsigned)ox < (unsigned)g.OW);
+            const unsigned e0 = (unsigned)((b * g.Cout + j0 + nn) * ohw + oy * g.OW + ox);
             yr[i][0] = buf_load_u4s(rdy, ok ? e0 * YE : kOOB, 0);
-            if constexpr (!Y16) yr[i][1] = buf_load_u4s(rdy, ok ? (e0 + 4u) * YE : kOOB, 0);
+            if constexpr (YRAW == 2) yr[i][1] = buf_load_u4s(rdy, ok ? (e0 + 4u) * YE : kOOB, 0);
         }
     };
     auto store_tile = [&](unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
+            const int pk = xi_pack[i];
             if (stid + i * 256 >= rp.nxitems) continue;
+            const int ci = pk >> 16, tb = (pk >> 8) & 255, j = pk & 255;       // (a channel past Cin: pk = -1 -> a zero block somewhere inside the buffer's x part)
+            const unsigned xl = pk >= 0 ? (unsigned)(ci * cpitch + (tb * rp.XR + j) * rowb + xi_xb * (IS == 2 ? 8 : 16)) : 0u;
             u32x4 pl[NPL];
-            if constexpr (UPS) {
+            if constexpr (F32) {
+                pl[0] = xr[i][0];
+            } else if constexpr (UPS) {
                 // every source pixel twice
                 if constexpr (X16) {
                     pl[0] = u32x4{__builtin_amdgcn_perm(xr[i][0][0], xr[i][0][0], 0x01000100u), __builtin_amdgcn_perm(xr[i][0][0], xr[i][0][0], 0x03020302u),
@@ -203,11 +215,15 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
             } else {
                 to_planes<ET, NPL, X16, SCALED>(xr[i], xsc, pl);
             }
+            if (pk < 0) continue;
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
-                unsigned char* d = buf + p * plane_bytes + xi_lds[i];
+                unsigned char* d = buf + p * plane_bytes + xl;
                 if (IS == 1) {
                     *reinterpret_cast<u32x4*>(d) = pl[p];
+                } else if (F32) {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(pl[p][0], pl[p][2]);                   // even columns
+                    *reinterpret_cast<uint2*>(d + (rowb >> 1)) = make_uint2(pl[p][1], pl[p][3]);     // odd columns
                 } else {
                     const uint2 ev = make_uint2(__builtin_amdgcn_perm(pl[p][1], pl[p][0], 0x05040100u), __builtin_amdgcn_perm(pl[p][3], pl[p][2], 0x05040100u));
                     const uint2 od = make_uint2(__builtin_amdgcn_perm(pl[p][1], pl[p][0], 0x07060302u), __builtin_amdgcn_perm(pl[p][3], pl[p][2], 0x07060302u));
@@ -218,11 +234,14 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
-            if (stid + i * 256 >= rp.nyitems) continue;
+            const int pk = yi_pack[i];
+            if (stid + i * 256 >= rp.nyitems || pk < 0) continue;
+            const unsigned yl = (unsigned)((pk >> 16) * dpitch + ((pk >> 8) & 255) * drowb + (pk & 255) * 16);
             u32x4 pl[NPL];
-            to_planes<ET, NPL, Y16, SCALED>(yr[i], ysc, pl);
+            if constexpr (F32) pl[0] = yr[i][0];
+            else to_planes<ET, NPL, Y16, SCALED>(yr[i], ysc, pl);
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(buf + NCI * cpitch + p * plane_bytes + yi_lds[i]) = pl[p];
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(buf + NCI * cpitch + p * plane_bytes + yl) = pl[p];
         }
     };
 
@@ -248,8 +267,8 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
         for (int p = 0; p < NPL; ++p) {
             const unsigned char* a = buf + NCI * cpitch + p * plane_bytes + ao;
             af[p].c = *reinterpret_cast<const u32x4*>(a);
-            af[p].l = *reinterpret_cast<const unsigned*>(a - 4);                // positions -2, -1
-            af[p].r = *reinterpret_cast<const unsigned*>(a + 16);               // positions 8, 9
+            af[p].l = *reinterpret_cast<const unsigned*>(a - 4);                // 16-bit: positions -2, -1;  fp32: position -1
+            af[p].r = *reinterpret_cast<const unsigned*>(a + 16);               // 16-bit: positions 8, 9;   fp32: position 4
         }
     };
 
@@ -259,6 +278,16 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // one tap's products of a k-step: av = the dy fragment in the tap's column shift, b = the x fragment of the tap's row (and parity)
+    auto tap_mfma = [&](f32x16 c, const u32x4 (&av)[NPL], const u32x4 (&b)[NPL]) {
+        if constexpr (F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[0][j]), __uint_as_float(b[0][j]), c, 0, 0, 0);
+            return c;
+        } else {
+            return mfma_split<ET, NPL>(av, b, c);
+        }
+    };
     // the k loop of one tile out of buffer `buf`
     auto k_loop = [&](const unsigned char* buf) {
         u32x4 bf[2][NB][NPL];
@@ -275,9 +304,9 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
                 const unsigned d[6] = {a.l, a.c[0], a.c[1], a.c[2], a.c[3], a.r};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    av[0][p][k] = alignbit16(d[k + 1], d[k]);
+                    av[0][p][k] = F32 ? d[k] : alignbit16(d[k + 1], d[k]);
                     av[1][p][k] = d[k + 1];
-                    av[2][p][k] = alignbit16(d[k + 2], d[k + 1]);
+                    av[2][p][k] = F32 ? d[k + 2] : alignbit16(d[k + 2], d[k + 1]);
                 }
             }
             const auto& b = bf[kk & 1];
@@ -286,15 +315,15 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma_split<ET, NPL>(av[2 - s], b[r], acc[r * 3 + s]);
+                    for (int s = 0; s < 3; ++s) acc[r * 3 + s] = tap_mfma(acc[r * 3 + s], av[2 - s], b[r]);
             } else {
                 // tap (rr, s): s = 0 -> (dy[j+1], odd), 1 -> (dy[j], even), 2 -> (dy[j], odd), 3 -> (dy[j-1], even)
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    acc[rr * 4 + 0] = mfma_split<ET, NPL>(av[2], b[rr * 2 + 1], acc[rr * 4 + 0]);
-                    acc[rr * 4 + 1] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 0], acc[rr * 4 + 1]);
-                    acc[rr * 4 + 2] = mfma_split<ET, NPL>(av[1], b[rr * 2 + 1], acc[rr * 4 + 2]);
-                    acc[rr * 4 + 3] = mfma_split<ET, NPL>(av[0], b[rr * 2 + 0], acc[rr * 4 + 3]);
+                    acc[rr * 4 + 0] = tap_mfma(acc[rr * 4 + 0], av[2], b[rr * 2 + 1]);
+                    acc[rr * 4 + 1] = tap_mfma(acc[rr * 4 + 1], av[1], b[rr * 2 + 0]);
+                    acc[rr * 4 + 2] = tap_mfma(acc[rr * 4 + 2], av[1], b[rr * 2 + 1]);
+                    acc[rr * 4 + 3] = tap_mfma(acc[rr * 4 + 3], av[0], b[rr * 2 + 0]);
                 }
             }
         }
@@ -376,8 +405,9 @@ int pow2ceil_log_w(int v) {
 
 template <int ET, int NPL, int GK, bool CI2, bool X16, bool Y16, bool UPS>
 void launch_rows(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
-    constexpr int NIX = GK == 2 ? 10 : (CI2 ? 8 : 4);
-    constexpr int NIY = GK == 2 ? 6 : (CI2 ? 5 : 10);
+    // staging items per thread (16-byte LDS blocks): the plan checks the geometry against these
+    constexpr int NIX = ET == 2 ? (GK == 2 ? 20 : (CI2 ? 16 : 8)) : (GK == 2 ? 10 : (CI2 ? 8 : 4));
+    constexpr int NIY = ET == 2 ? (GK == 2 ? 10 : (CI2 ? 9 : 18)) : (GK == 2 ? 6 : (CI2 ? 5 : 10));
     dim3 grid(p.jtiles, p.ngroups, p.psplit);
 #define AGAN_ROWS_LAUNCH(PC_)                                                                                                                         \
     do {                                                                                                                                              \
@@ -387,7 +417,7 @@ void launch_rows(const void* x, const void* dy, float* part, const Geom& g, cons
         hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
                            part, g, p, xs, ys);                                                                                                       \
     } while (0)
-    if constexpr (NPL == 1) {
+    if constexpr (NPL == 1 && ET != 2) {
         if (p.pc) { AGAN_ROWS_LAUNCH(true); return; }
     }
     AGAN_ROWS_LAUNCH(false);
@@ -397,8 +427,10 @@ template <int ET, int NPL, bool X16, bool Y16>
 void launch_rows_gk(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, hipStream_t st, const float* xs, const float* ys) {
     if (p.gk == 2) launch_rows<ET, NPL, 2, false, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
     else if (p.ups) {
-        if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
-        else launch_rows<ET, NPL, 0, false, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
+        if constexpr (ET != 2) {
+            if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
+            else launch_rows<ET, NPL, 0, false, X16, Y16, true>(x, dy, part, g, p, st, xs, ys);
+        }
     } else {
         if (p.ci2) launch_rows<ET, NPL, 0, true, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
         else launch_rows<ET, NPL, 0, false, X16, Y16, false>(x, dy, part, g, p, st, xs, ys);
@@ -441,15 +473,24 @@ RowsPlan plan_rows_wgrad(const Geom& gf, int prec, bool x16, bool y16, bool up) 
     p.ups = up ? 1 : 0;
     static const bool off = getenv("AGAN_WG_ROWS_OFF") != nullptr;
     if (off) return p;
-    const int planes = prec_planes(prec);
+    const bool f32 = prec == AGAN_PREC_F32;
+    static const bool nof32 = getenv("AGAN_WG_ROWS_NOF32") != nullptr;
+    if (f32 && (up || x16 || y16 || nof32)) return p;     // (fp32: the folded upsample kernel does 4 taps per pixel instead of 9 at the same rate)
+    const int planes = f32 ? 1 : prec_planes(prec);
     if (planes < 1 || planes > 2) return p;
     if ((x16 || y16) && planes != 1) return p;
+    const int pxl = f32 ? 2 : 3, PXB = 1 << pxl, ESZ = f32 ? 4 : 2;      // pixels per 16-byte LDS block
     if (g.OS != 1 || g.OY0 != -1 || g.DY != 1) return p;
     int IS, R;
     if (g.SY == 1 && g.R == 3 && g.S == 3) { p.gk = 0; IS = 1; R = 3; }
     else if (g.SY == 2 && g.R == 4 && g.S == 4) { p.gk = 2; IS = 2; R = 4; }
     else return p;
-    if (g.OW < 8 || (g.OW & 7) || g.IW != g.OW * IS || g.IH != g.OH * IS || g.Cin < 8 || g.Cout < 32) return p;
+    if (g.OW < PXB || (g.OW & (PXB - 1)) || g.IW != g.OW * IS || g.IH != g.OH * IS || g.Cin < 8 || g.Cout < 32) return p;
+    // fp32: measured against conv.hip's k-table kernel (profiles/r03_conv_micro_wgrad.txt): 10-20 % faster on the 3x3 layers of 64-128 channels
+    // (their K = 576 pads to 640 there), the same on the stride-2 layers (both sit at the sustained fp32-MFMA rate, ~120 TF/s), slower on the
+    // 4x4 maps -- so only the former come here
+    static const bool f32all = getenv("AGAN_WG_ROWS_F32_ALL") != nullptr;
+    if (f32 && !f32all && (p.gk != 0 || g.OW < 16)) return p;
     p.ci2 = (p.gk == 0 && g.Cout <= 64) ? 1 : 0;
     const int tpl = 7;
     p.twl = std::min(p.gk == 2 ? 5 : 6, pow2ceil_log_w(g.OW));
@@ -462,27 +503,30 @@ RowsPlan plan_rows_wgrad(const Geom& gf, int prec, bool x16, bool y16, bool up) 
     p.mtiles = p.tiles_x * p.tiles_y * p.tiles_b;
     p.XR = IS * (TH - 1) + R;
     p.XRT = TB * p.XR;
-    p.rowb = IS * TW * 2;
+    p.rowb = IS * TW * ESZ;
     // channel pitches = odd multiples of 16 bytes: the 8 lanes of a ds_read_b128 cycle hit 8 different 16-byte bank groups
     auto odd16 = [](int bytes) { const int q = (bytes + 15) / 16; return ((q & 1) ? q : q + 1) * 16; };
     p.cpitch = odd16(p.XRT * p.rowb + 16);
     p.halo = p.tiles_x > 1 ? 1 : 0;
     // a dy row = [left halo block][TW / 8 blocks][right halo block]; rows that never load a halo share it: the right neighbour of a row's last
     // block is the (always zero) left halo slot of the next row, the last row's is the channel's 16-byte pad
-    p.drowb = (TW / 8 + 1 + p.halo) * 16;
+    p.drowb = (TW / PXB + 1 + p.halo) * 16;
     p.dpitch = odd16(TB * TH * p.drowb + 16);
     p.bj = (p.gk == 2 || p.ci2) ? 64 : 128;
     const int nci = p.ci2 ? 64 : 32;
     p.plane_bytes = nci * p.cpitch + p.bj * p.dpitch;
     static const bool nopc = getenv("AGAN_WG_ROWS_NOPC") != nullptr;
-    p.pc = (!nopc && planes == 1 && 2 * p.plane_bytes <= 160 * 1024) ? 1 : 0;      // producer / consumer waves on two LDS buffers
+    p.pc = (!nopc && !f32 && planes == 1 && 2 * p.plane_bytes <= 160 * 1024) ? 1 : 0;      // producer / consumer waves on two LDS buffers
     p.smem_bytes = (p.pc ? 2 : 1) * planes * p.plane_bytes;
     if (p.smem_bytes > 160 * 1024) return p;
-    p.nxbl = pow2ceil_log_w(IS * TW / 8);
+    p.nxbl = pow2ceil_log_w(IS * TW / PXB);
     p.nxitems = nci * p.XRT << p.nxbl;
-    p.NBY = TW / 8 + 2 * p.halo;
+    p.NBY = TW / PXB + 2 * p.halo;
     p.nyitems = p.bj * TB * TH * p.NBY;
-    if (cdiv(p.nxitems, 256) > (p.gk == 2 ? 10 : (p.ci2 ? 8 : 4)) || cdiv(p.nyitems, 256) > (p.gk == 2 ? 6 : (p.ci2 ? 5 : 10))) return p;
+    // (items per thread the kernels are instantiated for: launch_rows; fp32 storage in a 16-bit mode loads a block as two 16-byte pieces)
+    const int nix = f32 ? (p.gk == 2 ? 20 : (p.ci2 ? 16 : 8)) : (p.gk == 2 ? 10 : (p.ci2 ? 8 : 4));
+    const int niy = f32 ? (p.gk == 2 ? 10 : (p.ci2 ? 9 : 18)) : (p.gk == 2 ? 6 : (p.ci2 ? 5 : 10));
+    if (cdiv(p.nxitems, 256) > nix || cdiv(p.nyitems, 256) > niy) return p;
     p.jtiles = cdiv(g.Cout, p.bj);
     p.nchunks = cdiv(g.Cin, 32);
     p.ngroups = cdiv(g.Cin, nci);
@@ -510,6 +554,7 @@ void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g
                        const float* x_scale, const float* dy_scale, bool x16, bool y16) {
     const Geom g = rows_geom(gf, p.ups != 0);
     switch (prec) {
+        case AGAN_PREC_F32: launch_rows_gk<2, 1, false, false>(x, dy, part, g, p, st, nullptr, nullptr); break;
         case AGAN_PREC_BF16: launch_rows_dt<0>(x, dy, part, g, p, st, x16, y16); break;
         case AGAN_PREC_F16: launch_rows_dt<1>(x, dy, part, g, p, st, x16, y16); break;
         case AGAN_PREC_BF16X3: launch_rows_gk<0, 2, false, false>(x, dy, part, g, p, st, nullptr, nullptr); break;
