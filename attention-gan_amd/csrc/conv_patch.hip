@@ -926,6 +926,34 @@ __device__ __forceinline__ void pack_patch_tile(const float* __restrict__ w, uns
     // rows of the block are contiguous in OIHW: (Bsz * kk) floats starting at [co0 + a][ci0][0][0]
     const int rowlen = T.Bsz * kk;
     const int nelem = T.A * rowlen;
+    if (((cin * kk) & 3) == 0) {
+        // 16-byte loads: 4 consecutive floats of a row per lane (rows are 16-byte aligned when cin * kh * kw is a multiple of 4; the block's
+        // row length Bsz * kk always is), a quarter of the load instructions and one row division per four elements.  The buffer range
+        // zero-fills what a partial channel chunk would read past the tensor's end.
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(w, (size_t)cout * cin * kk * sizeof(float));
+        for (int i0 = threadIdx.x * 4; i0 < nelem; i0 += 256 * 4 * 4) {       // 4 independent 16-byte loads in flight per thread
+            f32x4 v[4];
+            int a_[4], rem_[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * 1024;
+                const int a = drow.div(i), rem = i - a * rowlen;
+                a_[j] = a; rem_[j] = rem;
+                const int co = T.co0 + a;
+                v[j] = buf_load4(rw, (i < nelem && co < cout) ? (unsigned)(((size_t)co * cin + T.ci0) * kk + rem) * 4u : kOOB);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i0 + j * 1024 >= nelem) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rem = rem_[j] + e;
+                    const int ib = dkk.div(rem), tap = rem - ib * kk;
+                    tile[tap * kPackTile + a_[j] * T.Bsz + ib] = (T.ci0 + ib < cin) ? v[j][e] : 0.f;
+                }
+            }
+        }
+    } else
     for (int i0 = threadIdx.x; i0 < nelem; i0 += 256 * 8) {       // 8 independent loads in flight per thread
         float v[8];
         int dst[8];
