@@ -12,6 +12,7 @@ from ctypes import byref, c_void_p
 from typing import Dict, Optional, Tuple
 
 import contextlib
+import os
 import weakref
 
 import torch
@@ -451,7 +452,7 @@ def amax_of(t: Tensor) -> Tensor:
     return slot
 
 
-_AMAX_FUSE_MIN = 1 << 22      # elements: below this a separate agan_absmax launch (~5 us) is as cheap as the fused commit
+_AMAX_FUSE_MIN = int(os.environ.get("AGAN_AMAX_FUSE_MIN", 1 << 22))      # elements: below this a separate agan_absmax launch (~5 us) is as cheap as the fused commit
 
 
 def _amax_out(t: Tensor) -> Optional[Tensor]:
