@@ -119,8 +119,6 @@ __global__ __launch_bounds__(256) void conv_small_strip_kernel(const void* __res
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[p][n] = 0.f;
-    // (four channels per trip: 36 independent loads in flight per lane -- one channel at a time the kernel ran one memory latency per channel)
-#pragma unroll 4
     for (int c = 0; c < g.Cin; ++c) {
         const unsigned soff = (unsigned)(c * ihw);
         const float* wr = wk + (size_t)c * 9 * g.Nld;
@@ -256,7 +254,6 @@ __global__ __launch_bounds__(256) void wgrad_small_strip_kernel(const void* __re
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[t][n] = 0.f;
-#pragma unroll 2
     for (int sid = sbeg + threadIdx.x; sid < send; sid += 256) {
         const int xs = sid % W4, t1 = sid / W4, y = t1 % g.IH, b = t1 / g.IH;
         const int x0 = xs * 4;
