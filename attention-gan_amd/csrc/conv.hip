@@ -897,6 +897,10 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     const Geom gg = make_geom(g);
     prec = agan_conv_effective_prec(g, prec);
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(gg)) return 0;
+    if (prec == AGAN_PREC_F32) {
+        const WinoPlan wp = plan_wino(gg);
+        if (wp.ok) return std::max(wp.u_bytes, plan_gather(gg, prec).ws_bytes);      // (a call with a bias / activation epilogue takes the direct kernel)
+    }
     if (prec != AGAN_PREC_F32) {
         size_t a = plan_patch_gather(gg, make_patch_plan(gg)).ws_bytes;
         if (prec == AGAN_PREC_BF16 || prec == AGAN_PREC_F16)          // the row-block gather may split differently (either storage type)
@@ -1023,6 +1027,20 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
             return check_launch("conv_gather/sum_slabs");
         }
         return AGAN_OK;
+    }
+    if (prec == AGAN_PREC_F32 && in_dtype == AGAN_DT_F32 && out_dtype == AGAN_DT_F32 && !bias && act == AGAN_ACT_NONE && !lrelu_mask_v) {
+        // conv3x3 stride 1 (forward or data gradient) on enough pixels: Winograd F(2x2, 3x3), 2.25x fewer fp32 MFMAs (conv_wino.hip)
+        const WinoPlan wp = plan_wino(g);
+        if (wp.ok) {
+            if (wp.u_bytes > ws_bytes || !ws) {
+                set_error("conv_gather: workspace %zu < %zu", ws_bytes, wp.u_bytes);
+                return AGAN_EWORKSPACE;
+            }
+            timer_begin(st);
+            launch_wino(in, wk, out, g, wp, ws, st);
+            timer_end(st);
+            return check_launch("conv_gather/winograd");
+        }
     }
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {
         timer_begin(st);

@@ -314,6 +314,18 @@ struct RowsPlan {
     size_t slab, ws_bytes;
     FastDiv dXRT, dXR, dNBY;
 };
+// ---- Winograd F(2x2, 3x3) for the fp32 conv3x3 stride-1 gathers (conv_wino.hip) ----------------------------------------------------
+struct WinoPlan {
+    int ok;
+    int txl, tyl;                       // log2 of the tile block's columns / rows (2x2-output tiles); images per block = 32 >> (txl + tyl)
+    int blocks_x, blocks_y, blocks_b, mtiles;
+    int nf, ntiles;                     // cout fragments per workgroup (4: 128 channels, 2: 64), cout tiles
+    int pcp, raw_items, raw_bytes;      // raw patch: row pitch (floats), values per 8-channel chunk, LDS bytes
+    int smem_bytes;
+    size_t u_bytes;                     // transformed weights [16][Cin / 8][Nld][8] fp32: the call's workspace
+};
+WinoPlan plan_wino(const Geom& g);
+void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st);
 int prec_planes(int prec);
 RowsPlan plan_rows_wgrad(const Geom& g, int prec, bool x16, bool y16, bool up = false);
 void launch_rows_wgrad(const void* x, const void* dy, float* part, const Geom& g, const RowsPlan& p, int prec, hipStream_t st,

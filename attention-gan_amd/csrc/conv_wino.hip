@@ -1,0 +1,298 @@
+// Winograd F(2x2, 3x3) for the fp32 3x3 stride-1 convolutions (round 3): 16 multiplications per 2x2 outputs and channel pair instead of 36.
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A            d: 4x4 input patch, g: 3x3 kernel, Y: 2x2 outputs   (Lavin & Gray, correlation form)
+//
+// The fp32 conv kernels of this path sit at the sustained rate of the fp32 matrix pipe: the only way to make the
+// generator's 3x3 layers faster in exact fp32 arithmetic is to issue fewer MFMAs.  One workgroup owns 32 Winograd tiles (2x2 outputs each:
+// a 4 x 8 block of tiles, or smaller blocks of several images) x 128 (64) output channels and walks the input channels 8 at a time:
+//   * the raw 8-channel patch (tiles + 1-pixel halo) goes through LDS once; thread (tile, channel) transforms its 4x4 patch (32 adds) and
+//     writes the 16 transformed values V[position][tile][channel] back to LDS;
+//   * wave w multiplies the four positions (xi = 0..3, nu = w): D[cout][tile] += U[pos][cout][ci] V[pos][tile][ci] on
+//     v_mfma_f32_32x32x2_f32, four MFMAs per 16-byte fragment pair (a lane's 4 floats are k-steps j = 0..3, channel 4 * lh + j) --
+//     the transformed weights U come from a small transform pass over the mode's ordinary packed weights ([K][Nld]: forward and
+//     data-gradient packs alike, the latter already hold the flipped taps), laid out [pos][channel octet][cout][8];
+//   * the output transform runs along xi in registers (a lane holds all four xi of its tile and cout), along nu through LDS (the four
+//     waves), and leaves 2 x 2 pixels per lane as two 8-byte stores.
+// 16 accumulator fragments per wave (256 registers): one wave per SIMD.  No bias / activation epilogue: the layers that come here are
+// followed by BatchNorm (utilities/layers.py:45-53); calls with one fall back to the direct kernel.
+#include "conv_common.h"
+
+#include <cstdlib>
+#include <cstring>
+
+using namespace agan;
+using namespace agan::conv;
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_barrier_w() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// U[pos][ch8][n][8] = (G g G^T)[pos] of g = packed[k = (c, r, s)][n]
+__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ wk, float* __restrict__ U, int Kin, int Nld, int N) {
+    const int total = Kin * Nld;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int n = e % Nld, c = e / Nld;
+        float gk[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) gk[r][s] = n < N ? wk[(size_t)(c * 9 + r * 3 + s) * Nld + n] : 0.f;
+        // t = G g  (4 x 3),  u = t G^T (4 x 4);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        float t[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = gk[0][s];
+            t[1][s] = 0.5f * (gk[0][s] + gk[1][s] + gk[2][s]);
+            t[2][s] = 0.5f * (gk[0][s] - gk[1][s] + gk[2][s]);
+            t[3][s] = gk[2][s];
+        }
+        const int nch8 = Kin >> 3;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), u3 = t[xi][2];
+            const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) U[((size_t)((xi * 4 + nu) * nch8 + (c >> 3)) * Nld + n) * 8 + (c & 7)] = u[nu];
+        }
+    }
+}
+
+// NFW = cout fragments per workgroup: 4 (128 output channels x 32 tiles) or 2 (64 output channels x 64 tiles).  Wave w owns cout fragment
+// w % NFW of tile group w / NFW and ALL 16 transform positions of it (16 accumulator fragments = 256 registers, one wave per SIMD): a lane
+// then holds the whole 4 x 4 product of its (tile, output channel) and the output transform never leaves its registers.  (The first
+// version gave every wave one nu of all cout fragments: the nu-direction of the output transform went through 64 KB of LDS and four
+// barriers per workgroup -- with one workgroup per CU that epilogue and the prologue were a third of its time.)
+template <int NFW>
+__global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ out,
+                                                               const Geom g, const WinoPlan wp) {
+    constexpr int NTG = 4 / NFW;                                   // 32-tile groups per workgroup
+    constexpr int NTL = 32 * NTG;                                  // tiles per workgroup
+    constexpr int LT = NTG == 1 ? 5 : 6;                           // log2 of that
+    constexpr int NI = NTG == 1 ? 7 : 11;                          // raw staging values per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fw = w % NFW, tg = w / NFW;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int mt, nt;
+    {
+        const int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles);
+        nt = F % wp.ntiles; mt = F / wp.ntiles;
+    }
+    const int n0 = nt * (NFW * 32);
+    const int txl = wp.txl, tyl = wp.tyl;                           // log2 of the tile block's columns / rows; images = NTL >> (txl + tyl)
+    const int TX = 1 << txl, TY = 1 << tyl;
+    const int bxi = mt % wp.blocks_x, byi = (mt / wp.blocks_x) % wp.blocks_y, bbi = mt / (wp.blocks_x * wp.blocks_y);
+    const int tx0 = bxi << txl, ty0 = byi << tyl, tb0 = bbi << (LT - txl - tyl);
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const int PR = 2 * TY + 2, PC = 2 * TX + 2;                     // raw patch rows / columns per image
+    const int PCP = wp.pcp;                                        // row pitch (floats)
+    float* const raw = reinterpret_cast<float*>(lds);                               // [tb][8 ci][PR][PCP]
+    float* const V = reinterpret_cast<float*>(lds + wp.raw_bytes);                  // [2 buffers][16 pos][NTL tiles][8 ci]
+    constexpr int VBUF = 16 * NTL * 8;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(U, (size_t)16 * (g.Cin >> 3) * g.Nld * 8 * sizeof(float));
+    const int nch = g.Cin >> 3;
+
+    // ---- raw staging items: (image, channel, row, column), column fastest ----
+    unsigned it_lds[NI];
+    int it_off[NI];                       // element offset of (b, ci, row, col) relative to channel chunk 0, or -1
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int col = e % PC, t1 = e / PC;
+        const int row = t1 % PR, t2 = t1 / PR;
+        const int ci = t2 & 7, tb = t2 >> 3;
+        const int b = tb0 + tb, iy = 2 * ty0 - 1 + row, ix = 2 * tx0 - 1 + col;
+        const bool ok = (e < wp.raw_items) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+        it_off[i] = ok ? (b * g.Cin + ci) * ihw + iy * g.IW + ix : -1;
+        it_lds[i] = (unsigned)(((tb * 8 + ci) * PR + row) * PCP + col);
+    }
+    float rawv[NI];
+    auto load_raw = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            rawv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
+    };
+    auto store_raw = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tid + i * 256 < wp.raw_items) raw[it_lds[i]] = rawv[i];
+    };
+    // ---- input transform: thread (tile tt = (tid >> 3) + 32 k, channel ci = tid & 7) ----
+    const int tci = tid & 7;
+    auto transform = [&](float* Vb) {
+#pragma unroll
+        for (int k = 0; k < NTG; ++k) {
+            const int tt = (tid >> 3) + 32 * k;
+            const int ttx = tt & (TX - 1), tty = (tt >> txl) & (TY - 1), ttb = tt >> (txl + tyl);
+            const float* const tsrc = raw + ((ttb * 8 + tci) * PR + 2 * tty) * PCP + 2 * ttx;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(tsrc + i * PCP), b = *reinterpret_cast<const float2*>(tsrc + i * PCP + 2);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
+            }
+            // t = B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3); v = t B: columns likewise
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const float v0 = t[xi][0] - t[xi][2], v1 = t[xi][1] + t[xi][2], v2 = t[xi][2] - t[xi][1], v3 = t[xi][1] - t[xi][3];
+                Vb[((xi * 4 + 0) * NTL + tt) * 8 + tci] = v0;
+                Vb[((xi * 4 + 1) * NTL + tt) * 8 + tci] = v1;
+                Vb[((xi * 4 + 2) * NTL + tt) * 8 + tci] = v2;
+                Vb[((xi * 4 + 3) * NTL + tt) * 8 + tci] = v3;
+            }
+        }
+    };
+    // ---- transformed weights: this wave's cout fragment, 16 bytes (channels 4 * lh ..) per lane and position; half a chunk's positions
+    //      (8) at a time, so that two register sets of 8 fragments suffice ----
+    const unsigned ulane = (unsigned)(min(n0 + fw * 32 + l31, g.Nld - 1) * 32 + lh * 16);      // (rows past Cout are zero in U)
+    auto load_u = [&](int ch, int half, u32x4 (&uf)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            uf[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rU, ulane, (unsigned)(((half * 8 + q) * nch + min(ch, nch - 1)) * g.Nld) * 32u, 0));
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    u32x4 ua[8], ub[8];                  // weights of positions 0..7 / 8..15: each set is reloaded while the other one's products run
+    auto half_products = [&](const float* Vc, int half, const u32x4 (&uf)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pos = half * 8 + q;
+            const u32x4 vf = *reinterpret_cast<const u32x4*>(Vc + (pos * NTL + tg * 32 + l31) * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[q][j]), __uint_as_float(vf[j]), acc[pos], 0, 0, 0);
+        }
+    };
+    load_raw(0);
+    load_u(0, 0, ua);
+    store_raw();
+    lds_barrier_w();
+    transform(V);
+    if (nch > 1) load_raw(1);
+    lds_barrier_w();
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Vc = V + (ch & 1) * VBUF;
+        const bool more = ch + 1 < nch;
+        if (more) {
+            store_raw();                                      // the raw patch of chunk ch + 1 (loaded one chunk ago) into LDS
+            lds_barrier_w();                                  // ... complete
+        }
+        // one scheduling region: this chunk's 64 MFMAs and, in their shadow, the input transform of the next chunk, the weight fragments of
+        // the next half chunk and the raw loads of chunk ch + 2
+        load_u(ch, 1, ub);                                    // second half of this chunk
+        half_products(Vc, 0, ua);
+        if (more) transform(V + ((ch + 1) & 1) * VBUF);
+        load_u(ch + 1, 0, ua);                                // first half of the next chunk (past the end: a harmless repeat)
+        if (ch + 2 < nch) load_raw(ch + 2);
+        half_products(Vc, 1, ub);
+        lds_barrier_w();                                      // V of chunk ch + 1 is complete, every wave is done with chunk ch's V and with the raw patch
+    }
+
+    // ---- output transform, in registers: Y = A^T M A with M[xi][nu] = acc[xi * 4 + nu], A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] ----
+    const int lt = tg * 32 + l31;
+    const int tx = lt & (TX - 1), ty = (lt >> txl) & (TY - 1), tb = lt >> (txl + tyl);
+    const int b = tb0 + tb, oy = 2 * (ty0 + ty), ox = 2 * (tx0 + tx);
+    const bool pvalid = (b < g.B) & (oy < g.OH) & (ox < g.OW);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int nw = n0 + fw * 32;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0[4], c1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            c0[nu] = acc[0 + nu][r] + acc[4 + nu][r] + acc[8 + nu][r];
+            c1[nu] = acc[4 + nu][r] - acc[8 + nu][r] - acc[12 + nu][r];
+        }
+        const float y00 = c0[0] + c0[1] + c0[2], y01 = c0[1] - c0[2] - c0[3];
+        const float y10 = c1[0] + c1[1] + c1[2], y11 = c1[1] - c1[2] - c1[3];
+        const int n = nw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = pvalid & (n < g.Cout);
+        const unsigned off = (unsigned)((b * g.Cout + n) * ohw + oy * g.OW + ox) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{y00, y01}), ro, ok ? off : kOOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{y10, y11}), ro, ok ? off + (unsigned)g.OW * 4u : kOOB, 0, 0);
+    }
+}
+
+int pow2floor_log(int v) {
+    int l = 0;
+    while ((2 << l) <= v) ++l;
+    return l;
+}
+
+}  // namespace
+
+namespace agan {
+namespace conv {
+
+// Plan of the Winograd kernel for gather geometry g (forward or data gradient of a conv3x3 stride 1 pad 1); p.ok == 0: not taken.
+WinoPlan plan_wino(const Geom& g) {
+    WinoPlan p;
+    memset(&p, 0, sizeof(p));
+    static const bool off = getenv("AGAN_WINO_OFF") != nullptr;
+    if (off) return p;
+    if (!(g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1)) return p;
+    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 1) || (g.Cin & 7) || g.Cout < 32) return p;
+    const int tw = g.OW / 2, th = g.OH / 2;                   // tiles per row / column
+    if (tw < 4) return p;                                     // (4x4 maps: two tiles per row -- the direct kernel's K split serves them better)
+    p.nf = g.Cout >= 96 ? 4 : 2;                             // cout fragments per workgroup; 4: 32 tiles, 2: 64 tiles
+    const int lt = p.nf == 4 ? 5 : 6;
+    p.txl = std::min(3, pow2floor_log(tw));
+    p.tyl = std::min(lt - p.txl, pow2floor_log(th));
+    const int TX = 1 << p.txl, TY = 1 << p.tyl, TB = (1 << lt) >> (p.txl + p.tyl);
+    p.blocks_x = cdiv(tw, TX);
+    p.blocks_y = cdiv(th, TY);
+    p.blocks_b = cdiv(g.B, TB);
+    p.mtiles = p.blocks_x * p.blocks_y * p.blocks_b;
+    p.ntiles = cdiv(g.Cout, p.nf * 32);
+    // the 32 x 32 x 2 product needs thousands of tiles to pay for a workgroup's 256 accumulators: small layers stay on the direct kernel
+    if (p.mtiles * p.ntiles < 256) return p;
+    const int PR = 2 * TY + 2, PC = 2 * TX + 2;
+    p.pcp = (PC + 1) & ~1;
+    p.raw_items = TB * 8 * PR * PC;
+    if (p.raw_items > (p.nf == 4 ? 7 : 11) * 256) return p;
+    p.raw_bytes = (TB * 8 * PR * p.pcp * 4 + 15) & ~15;
+    p.smem_bytes = p.raw_bytes + 2 * 16 * (1 << lt) * 8 * 4;
+    p.u_bytes = (size_t)16 * (g.Cin / 8) * g.Nld * 8 * sizeof(float);
+    p.ok = 1;
+    return p;
+}
+
+// wk: the mode's ordinary fp32 pack [K = (c, r, s)][Nld]; ws: >= p.u_bytes
+void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st) {
+    float* U = static_cast<float*>(ws);
+    const int total = g.Cin * g.Nld;
+    hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+    dim3 grid(p.mtiles * p.ntiles);
+    if (p.nf == 4) {
+        static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)a4;
+        hipLaunchKernelGGL(conv_wino_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+    } else {
+        static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)a2;
+        hipLaunchKernelGGL(conv_wino_f32_kernel<2>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+    }
+}
+
+}  // namespace conv
+}  // namespace agan
