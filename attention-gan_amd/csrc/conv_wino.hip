@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
     const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
     const int PR = 2 * TY + 2, PC = 2 * TX + 2;                     // raw patch rows / columns per image
     const int PCP = wp.pcp;                                        // row pitch (floats)
-    float* const raw = reinterpret_cast<float*>(lds);                               // [tb][8 ci][PR][PCP]
-    float* const V = reinterpret_cast<float*>(lds + wp.raw_bytes);                  // [2 buffers][16 pos][NTL tiles][8 ci]
+    float* const raw = reinterpret_cast<float*>(lds);                               // [2 buffers][tb][8 ci][PR][PCP]
+    const int RAWBUF = wp.raw_bytes >> 2;                                           // floats per raw buffer
+    float* const V = reinterpret_cast<float*>(lds + 2 * wp.raw_bytes);              // [2 buffers][16 pos][NTL tiles][8 ci]
     constexpr int VBUF = 16 * NTL * 8;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
     const __amdgpu_buffer_rsrc_t rU = make_rsrc(U, (size_t)16 * (g.Cin >> 3) * g.Nld * 8 * sizeof(float));
@@ -111,19 +112,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
         it_lds[i] = (unsigned)(((tb * 8 + ci) * PR + row) * PCP + col);
     }
     float rawv[NI];
-    auto load_raw = [&](int ch) {
+    auto load_raw = [&](int ch, float (&rv)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            rawv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
+            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
     };
-    auto store_raw = [&]() {
+    auto store_raw = [&](int ch, const float (&rv)[NI]) {      // chunk ch's patch -> raw buffer ch & 1
+        float* const rb = raw + (ch & 1) * RAWBUF;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (tid + i * 256 < wp.raw_items) raw[it_lds[i]] = rawv[i];
+            if (tid + i * 256 < wp.raw_items) rb[it_lds[i]] = rv[i];
     };
     // ---- input transform: thread (tile tt = (tid >> 3) + 32 k, channel ci = tid & 7) ----
     const int tci = tid & 7;
-    auto transform = [&](float* Vb) {
+    auto transform = [&](float* Vb) {                          // (the prologue's: chunk 0, raw buffer 0)
 #pragma unroll
         for (int k = 0; k < NTG; ++k) {
             const int tt = (tid >> 3) + 32 * k;
@@ -171,39 +173,73 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
     u32x4 ua[8], ub[8];                  // weights of positions 0..7 / 8..15: each set is reloaded while the other one's products run
-    auto half_products = [&](const float* Vc, int half, const u32x4 (&uf)[8]) {
+    // transform of the next chunk, in 4 * NTG pieces (one output row xi of one tile group each) that ride between the MFMA groups
+    float td[NTG][4][4];
+    auto transform_piece = [&](const float* rb, float* Vb, int pi) {
+        const int k = pi >> 2, xi = pi & 3;
+        const int tt = (tid >> 3) + 32 * k;
+        if (xi == 0) {
+            const int ttx = tt & (TX - 1), tty = (tt >> txl) & (TY - 1), ttb = tt >> (txl + tyl);
+            const float* const tsrc = rb + ((ttb * 8 + tci) * PR + 2 * tty) * PCP + 2 * ttx;
+            float d[4][4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int pos = half * 8 + q;
-            const u32x4 vf = *reinterpret_cast<const u32x4*>(Vc + (pos * NTL + tg * 32 + l31) * 8 + lh * 4);
+            for (int i = 0; i < 4; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(tsrc + i * PCP), b = *reinterpret_cast<const float2*>(tsrc + i * PCP + 2);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[q][j]), __uint_as_float(vf[j]), acc[pos], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {                       // t = B^T d
+                td[k][0][j] = d[0][j] - d[2][j];
+                td[k][1][j] = d[1][j] + d[2][j];
+                td[k][2][j] = d[2][j] - d[1][j];
+                td[k][3][j] = d[1][j] - d[3][j];
+            }
         }
+        const float v0 = td[k][xi][0] - td[k][xi][2], v1 = td[k][xi][1] + td[k][xi][2], v2 = td[k][xi][2] - td[k][xi][1], v3 = td[k][xi][1] - td[k][xi][3];
+        Vb[((xi * 4 + 0) * NTL + tt) * 8 + tci] = v0;
+        Vb[((xi * 4 + 1) * NTL + tt) * 8 + tci] = v1;
+        Vb[((xi * 4 + 2) * NTL + tt) * 8 + tci] = v2;
+        Vb[((xi * 4 + 3) * NTL + tt) * 8 + tci] = v3;
     };
-    load_raw(0);
-    load_u(0, 0, ua);
-    store_raw();
-    lds_barrier_w();
-    transform(V);
-    if (nch > 1) load_raw(1);
-    lds_barrier_w();
+    {   // prologue: the patches of chunks 0 and 1 in flight together, chunk 0 transformed
+        float rawv1[NI];
+        load_raw(0, rawv);
+        if (nch > 1) load_raw(1, rawv1);
+        load_u(0, 0, ua);
+        store_raw(0, rawv);
+        if (nch > 1) store_raw(1, rawv1);
+        lds_barrier_w();
+        transform(V);
+        lds_barrier_w();
+    }
     for (int ch = 0; ch < nch; ++ch) {
         const float* Vc = V + (ch & 1) * VBUF;
+        float* Vn = V + ((ch + 1) & 1) * VBUF;
+        const float* rn = raw + ((ch + 1) & 1) * RAWBUF;      // the raw patch of chunk ch + 1: in LDS since the last barrier
         const bool more = ch + 1 < nch;
-        if (more) {
-            store_raw();                                      // the raw patch of chunk ch + 1 (loaded one chunk ago) into LDS
-            lds_barrier_w();                                  // ... complete
+        // 16 stages, one per transform position: [V fragment of the NEXT stage] [a piece of the other work] [this stage's 4 MFMAs = 256
+        // cycles of the matrix pipe].  The wave issues in order, so whatever must hide behind the MFMAs has to stand between them in
+        // program order; sched_barrier pins the stages.  Other work of chunk ch: the input transform of chunk ch + 1 (stages 1 .. 4 NTG),
+        // the global loads of chunk ch + 2's raw patch (stage 1) and its LDS stores (stage 14, into the buffer chunk ch's patch has left),
+        // the weight fragments (stages 0 and 8).  ONE barrier per chunk.
+        const unsigned vlane = (unsigned)((tg * 32 + l31) * 8 + lh * 4);
+        u32x4 vf[2];
+        vf[0] = *reinterpret_cast<const u32x4*>(Vc + vlane);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            if (pos + 1 < 16) vf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(Vc + (pos + 1) * NTL * 8 + vlane);
+            if (pos == 0) load_u(ch, 1, ub);                  // second half of this chunk's weights
+            if (pos == 1 && ch + 2 < nch) load_raw(ch + 2, rawv);
+            if (pos == 8) load_u(ch + 1, 0, ua);              // first half of the next chunk's (past the end: a harmless repeat)
+            if (more && pos >= 1 && pos <= 4 * NTG) transform_piece(rn, Vn, pos - 1);
+            if (pos == 14 && ch + 2 < nch) store_raw(ch + 2, rawv);
+            const u32x4 uf = pos < 8 ? ua[pos & 7] : ub[pos & 7];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[j]), __uint_as_float(vf[pos & 1][j]), acc[pos], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // one scheduling region: this chunk's 64 MFMAs and, in their shadow, the input transform of the next chunk, the weight fragments of
-        // the next half chunk and the raw loads of chunk ch + 2
-        load_u(ch, 1, ub);                                    // second half of this chunk
-        half_products(Vc, 0, ua);
-        if (more) transform(V + ((ch + 1) & 1) * VBUF);
-        load_u(ch + 1, 0, ua);                                // first half of the next chunk (past the end: a harmless repeat)
-        if (ch + 2 < nch) load_raw(ch + 2);
-        half_products(Vc, 1, ub);
-        lds_barrier_w();                                      // V of chunk ch + 1 is complete, every wave is done with chunk ch's V and with the raw patch
+        lds_barrier_w();                                      // V of chunk ch + 1 and the raw patch of chunk ch + 2 are complete; every wave is done with chunk ch
     }
 
     // ---- output transform, in registers: Y = A^T M A with M[xi][nu] = acc[xi * 4 + nu], A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] ----
@@ -271,7 +307,7 @@ WinoPlan plan_wino(const Geom& g) {
     p.raw_items = TB * 8 * PR * PC;
     if (p.raw_items > (p.nf == 4 ? 7 : 11) * 256) return p;
     p.raw_bytes = (TB * 8 * PR * p.pcp * 4 + 15) & ~15;
-    p.smem_bytes = p.raw_bytes + 2 * 16 * (1 << lt) * 8 * 4;
+    p.smem_bytes = 2 * p.raw_bytes + 2 * 16 * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
     p.u_bytes = (size_t)16 * (g.Cin / 8) * g.Nld * 8 * sizeof(float);
     p.ok = 1;
     return p;

@@ -26,6 +26,7 @@ LAYERS = {
     "g_same_64_128": ("same", 24, 64, 128, 128, 3),
     "g_same_64_64": ("same", 24, 64, 128, 64, 3),
     "g_up_64_64": ("up", 24, 64, 128, 64, 3),
+    "syn_same_256_128": ("same", 24, 256, 64, 128, 3),      # synthetic: a long K loop (32 Winograd chunks) on 64^2 maps
     "rgb_head_256": ("same", 24, 32, 256, 3, 3),      # GET_IMAGE_G of stage 3 (<= 4 output channels: conv_small.hip)
     "rgb_head_128": ("same", 24, 32, 128, 3, 3),
 }
