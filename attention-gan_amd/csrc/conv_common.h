@@ -324,6 +324,12 @@ struct WinoPlan {
     int smem_bytes;
     size_t u_bytes;                     // transformed weights [16][Cin / 8][Nld][8] fp32: the call's workspace
 };
+struct WinoWgradPlan {
+    int ok, noct, jtiles, itiles, psplit, octs_per_split, smem_bytes;      // tile octets; 64-channel tiles; pixel split
+    size_t slab, ws_bytes;
+};
+WinoWgradPlan plan_wino_wgrad(const Geom& g);
+void launch_wino_wgrad(const float* x, const float* dy, float* part, const Geom& g, const WinoWgradPlan& p, hipStream_t st);
 WinoPlan plan_wino(const Geom& g);
 void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st);
 int prec_planes(int prec);

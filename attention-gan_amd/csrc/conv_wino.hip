@@ -269,6 +269,159 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers, Winograd F(3x3, 2x2):  dw[r][s] = sum over 2x2 dy tiles e  of  corr(d, e)[r][s],  d = the tile's
+// 4x4 x patch:   dw = A^T [ sum_tiles (G e G^T) (.) (B^T d B) ] A     A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]],
+//                G = [[1,0],[.5,.5],[.5,-.5],[0,1]],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]]      (16 products per tile instead of 36).
+// The contraction index of the 16 products is the TILE: both operands are transformed activations, staged [position][channel][8 tiles]
+// in LDS (a lane's 16 bytes = 4 k-steps of its channel), produced by the threads straight from global memory (a thread loads its tile's
+// 4x4 x patch / 2x2 dy tile, transforms it and writes 16 values; no raw copy in LDS).  A workgroup owns 64 output x 64 input channels
+// (wave = one 32 x 32 fragment pair, all 16 positions: 256 accumulator registers, output transform in registers) and a range of tile
+// octets; per octet 64 MFMAs per wave, ONE barrier.  Partial results [cout][cin][3][3] per pixel split, summed by sum_slabs_kernel.
+__global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                                     const Geom g, const WinoWgradPlan wp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int ZV = 16 * 64 * 8;                               // floats of one operand image [pos][64 channels][8 tiles]
+    float* const L = reinterpret_cast<float*>(lds);               // [2 buffers][Z | V]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = w & 1, fi = w >> 1;                            // cout / cin fragment of this wave
+    const int l31 = lane & 31, lh = lane >> 5;
+    int jt, it, split;
+    {
+        int F = xcd_contiguous(linear_block_id(), wp.jtiles * wp.itiles * wp.psplit);
+        jt = F % wp.jtiles; F /= wp.jtiles;
+        it = F % wp.itiles; split = F / wp.itiles;
+    }
+    const int j0 = jt * 64, i0 = it * 64;
+    const int ihw = g.IH * g.IW;
+    const int o_beg = split * wp.octs_per_split, o_end = min(wp.noct, o_beg + wp.octs_per_split);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, (size_t)g.B * g.Cout * ihw * sizeof(float));
+    const int tw8 = g.OW >> 4, th = g.OH >> 1;                    // tile octets per row, tile rows per image
+
+    // this thread's two (tile, channel) pairs of each operand: tile = tid & 7, channel = (tid >> 3) + 32 k
+    const int tj = tid & 7, tc = tid >> 3;
+    float xr[2][16];
+    float2 dr[2][2];
+    auto load_oct = [&](int o) {
+        const bool ov = o < o_end;
+        const int txo = o % tw8, t1 = o / tw8;
+        const int ty = t1 % th, b = t1 / th;
+        const int tx = txo * 8 + tj;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ci = i0 + tc + 32 * k, co = j0 + tc + 32 * k;
+            const bool cv = ov & (ci < g.Cin), dv = ov & (co < g.Cout);
+            const int xbase = (b * g.Cin + ci) * ihw, dbase = (b * g.Cout + co) * ihw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = 2 * ty - 1 + i;
+                const bool rv = cv & ((unsigned)iy < (unsigned)g.IH);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ix = 2 * tx - 1 + c;
+                    xr[k][i * 4 + c] = buf_load(rx, (rv & ((unsigned)ix < (unsigned)g.IW)) ? (unsigned)(xbase + iy * g.IW + ix) * 4u : kOOB);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                dr[k][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rd, dv ? (unsigned)(dbase + (2 * ty + a) * g.OW + 2 * tx) * 4u : kOOB, 0, 0));
+        }
+    };
+    auto transform_store = [&](float* buf) {                     // buf: Z at 0, V at ZV
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = tc + 32 * k;
+            {   // V = B^T d B
+                float t[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d0 = xr[k][c], d1 = xr[k][4 + c], d2 = xr[k][8 + c], d3 = xr[k][12 + c];
+                    t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d3 - d1;
+                }
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    const float v0 = t[xi][0] - t[xi][2], v1 = t[xi][1] + t[xi][2], v2 = t[xi][2] - t[xi][1], v3 = t[xi][3] - t[xi][1];
+                    float* o = buf + ZV + ((xi * 4) * 64 + ch) * 8 + tj;
+                    o[0] = v0; o[64 * 8] = v1; o[2 * 64 * 8] = v2; o[3 * 64 * 8] = v3;
+                }
+            }
+            {   // Z = G e G^T
+                const float e00 = dr[k][0].x, e01 = dr[k][0].y, e10 = dr[k][1].x, e11 = dr[k][1].y;
+                const float u[4][2] = {{e00, e01}, {0.5f * (e00 + e10), 0.5f * (e01 + e11)}, {0.5f * (e00 - e10), 0.5f * (e01 - e11)}, {e10, e11}};
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    float* o = buf + ((xi * 4) * 64 + ch) * 8 + tj;
+                    o[0] = u[xi][0]; o[64 * 8] = 0.5f * (u[xi][0] + u[xi][1]); o[2 * 64 * 8] = 0.5f * (u[xi][0] - u[xi][1]); o[3 * 64 * 8] = u[xi][1];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    if (o_beg < o_end) {
+        load_oct(o_beg);
+        transform_store(L);
+        load_oct(o_beg + 1);
+        lds_barrier_w();
+        const unsigned zl = (unsigned)((fj * 32 + l31) * 8 + lh * 4), vl = (unsigned)(ZV + (fi * 32 + l31) * 8 + lh * 4);
+        for (int o = o_beg; o < o_end; ++o) {
+            const float* cur = L + ((o - o_beg) & 1) * (2 * ZV);
+            float* nxt = L + (((o - o_beg) & 1) ^ 1) * (2 * ZV);
+            // the next octet's operands (its patches were loaded one octet ago) are transformed and written, the octet after that is loaded,
+            // all in the shadow of this octet's 64 MFMAs -- pinned stage by stage as in the gather kernel
+            u32x4 zf[2], vf[2];
+            zf[0] = *reinterpret_cast<const u32x4*>(cur + zl);
+            vf[0] = *reinterpret_cast<const u32x4*>(cur + vl);
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                if (pos + 1 < 16) {
+                    zf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + zl);
+                    vf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + vl);
+                }
+                if (pos == 1 && o + 1 < o_end) transform_store(nxt);
+                if (pos == 3) load_oct(o + 2);                  // (past the range: zero range, nothing is fetched)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zf[pos & 1][j]), __uint_as_float(vf[pos & 1][j]), acc[pos], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier_w();
+        }
+    }
+
+    // ---- dw = A^T M A in registers; D[cout][cin]: lane l31 = input channel, register -> output channel; 9 taps contiguous in OIHW ----
+    float* const o = part + (size_t)split * wp.slab;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)g.Cout * g.Cin * 9 * sizeof(float));
+    const int ci = i0 + fi * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c[3][4];                                           // rows of A^T M
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const float m0 = acc[nu][r], m1 = acc[4 + nu][r], m2 = acc[8 + nu][r], m3 = acc[12 + nu][r];
+            c[0][nu] = m0 + m1 + m2;
+            c[1][nu] = m1 - m2;
+            c[2][nu] = m1 + m2 + m3;
+        }
+        const int co = j0 + fj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = (co < g.Cout) & (ci < g.Cin);
+        const unsigned base = (unsigned)((co * g.Cin + ci) * 9) * 4u;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 0) * 4u : kOOB, c[rr][0] + c[rr][1] + c[rr][2]);
+            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 1) * 4u : kOOB, c[rr][1] - c[rr][2]);
+            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 2) * 4u : kOOB, c[rr][1] + c[rr][2] + c[rr][3]);
+        }
+    }
+}
+
 int pow2floor_log(int v) {
     int l = 0;
     while ((2 << l) <= v) ++l;
@@ -328,6 +481,36 @@ void launch_wino(const float* in, const float* wk, float* out, const Geom& g, co
         (void)a2;
         hipLaunchKernelGGL(conv_wino_f32_kernel<2>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
     }
+}
+
+
+// Winograd weight gradient of a conv3x3 stride 1 pad 1 (forward geometry g); p.ok == 0: not taken.
+WinoWgradPlan plan_wino_wgrad(const Geom& g) {
+    WinoWgradPlan p;
+    memset(&p, 0, sizeof(p));
+    static const bool off = getenv("AGAN_WINO_OFF") != nullptr || getenv("AGAN_WINO_WGRAD_OFF") != nullptr;
+    if (off) return p;
+    if (!(g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1)) return p;
+    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 15) || g.Cin < 32 || g.Cout < 32) return p;
+    p.noct = g.B * (g.OH / 2) * (g.OW / 16);
+    p.jtiles = cdiv(g.Cout, 64);
+    p.itiles = cdiv(g.Cin, 64);
+    const int wgs = p.jtiles * p.itiles;
+    if (p.noct < 64 * 16 || wgs > 256) return p;               // enough pixels to split over the chip with long loops; (many-channel layers have few pixels here)
+    const int ps = std::max(1, std::min(256 / wgs, p.noct / 16));
+    p.octs_per_split = cdiv(p.noct, ps);
+    p.psplit = cdiv(p.noct, p.octs_per_split);
+    p.slab = ((size_t)g.Cout * g.Cin * 9 + 3) / 4 * 4;
+    p.ws_bytes = p.slab * p.psplit * sizeof(float);
+    p.smem_bytes = 2 * 2 * 16 * 64 * 8 * 4;
+    p.ok = 1;
+    return p;
+}
+
+void launch_wino_wgrad(const float* x, const float* dy, float* part, const Geom& g, const WinoWgradPlan& p, hipStream_t st) {
+    static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)a;
+    hipLaunchKernelGGL(conv_wino_wgrad_f32_kernel, dim3(p.jtiles * p.itiles * p.psplit), dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p);
 }
 
 }  // namespace conv
