@@ -304,59 +304,75 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float
     const int tj = tid & 7, tc = tid >> 3;
     float xr[2][16];
     float2 dr[2][2];
-    auto load_oct = [&](int o) {
+    // loads of octet o in 4 pieces (pair k = lp >> 1; x rows 2 * (lp & 1), +1; the dy tile with the first half)
+    auto load_piece = [&](int o, int lp) {
         const bool ov = o < o_end;
         const int txo = o % tw8, t1 = o / tw8;
         const int ty = t1 % th, b = t1 / th;
         const int tx = txo * 8 + tj;
+        const int k = lp >> 1, half = lp & 1;
+        const int ci = i0 + tc + 32 * k, co = j0 + tc + 32 * k;
+        const bool cv = ov & (ci < g.Cin);
+        const int xbase = (b * g.Cin + ci) * ihw + 2 * tx - 1;
+        const bool c0ok = tx > 0, c3ok = 2 * tx + 2 < g.IW;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ci = i0 + tc + 32 * k, co = j0 + tc + 32 * k;
-            const bool cv = ov & (ci < g.Cin), dv = ov & (co < g.Cout);
-            const int xbase = (b * g.Cin + ci) * ihw, dbase = (b * g.Cout + co) * ihw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int iy = 2 * ty - 1 + i;
-                const bool rv = cv & ((unsigned)iy < (unsigned)g.IH);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ix = 2 * tx - 1 + c;
-                    xr[k][i * 4 + c] = buf_load(rx, (rv & ((unsigned)ix < (unsigned)g.IW)) ? (unsigned)(xbase + iy * g.IW + ix) * 4u : kOOB);
-                }
-            }
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * half + ii;
+            const int iy = 2 * ty - 1 + i;
+            const bool rv = cv & ((unsigned)iy < (unsigned)g.IH);
+            const unsigned ro = (unsigned)(xbase + iy * g.IW) * 4u;
+            xr[k][i * 4 + 0] = buf_load(rx, (rv & c0ok) ? ro : kOOB);
+            xr[k][i * 4 + 1] = buf_load(rx, rv ? ro + 4u : kOOB);
+            xr[k][i * 4 + 2] = buf_load(rx, rv ? ro + 8u : kOOB);
+            xr[k][i * 4 + 3] = buf_load(rx, (rv & c3ok) ? ro + 12u : kOOB);
+        }
+        if (half == 0) {
+            const bool dv = ov & (co < g.Cout);
+            const int dbase = (b * g.Cout + co) * ihw + 2 * ty * g.OW + 2 * tx;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
-                dr[k][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rd, dv ? (unsigned)(dbase + (2 * ty + a) * g.OW + 2 * tx) * 4u : kOOB, 0, 0));
+                dr[k][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rd, dv ? (unsigned)(dbase + a * g.OW) * 4u : kOOB, 0, 0));
         }
     };
-    auto transform_store = [&](float* buf) {                     // buf: Z at 0, V at ZV
+    auto load_oct = [&](int o) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ch = tc + 32 * k;
-            {   // V = B^T d B
-                float t[4][4];
+        for (int lp = 0; lp < 4; ++lp) load_piece(o, lp);
+    };
+    // transform + LDS stores of the loaded octet in 8 pieces (pair k = tp >> 2; V rows 0-1, V rows 2-3, Z rows 0-1, Z rows 2-3)
+    float tt_[2][4][4];                                          // t = B^T d of pair k, kept between its two V pieces
+    auto transform_piece = [&](float* buf, int tp) {             // buf: Z at 0, V at ZV
+        const int k = tp >> 2, sub = tp & 3;
+        const int ch = tc + 32 * k;
+        if (sub == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float d0 = xr[k][c], d1 = xr[k][4 + c], d2 = xr[k][8 + c], d3 = xr[k][12 + c];
-                    t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d3 - d1;
-                }
-#pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    const float v0 = t[xi][0] - t[xi][2], v1 = t[xi][1] + t[xi][2], v2 = t[xi][2] - t[xi][1], v3 = t[xi][3] - t[xi][1];
-                    float* o = buf + ZV + ((xi * 4) * 64 + ch) * 8 + tj;
-                    o[0] = v0; o[64 * 8] = v1; o[2 * 64 * 8] = v2; o[3 * 64 * 8] = v3;
-                }
-            }
-            {   // Z = G e G^T
-                const float e00 = dr[k][0].x, e01 = dr[k][0].y, e10 = dr[k][1].x, e11 = dr[k][1].y;
-                const float u[4][2] = {{e00, e01}, {0.5f * (e00 + e10), 0.5f * (e01 + e11)}, {0.5f * (e00 - e10), 0.5f * (e01 - e11)}, {e10, e11}};
-#pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    float* o = buf + ((xi * 4) * 64 + ch) * 8 + tj;
-                    o[0] = u[xi][0]; o[64 * 8] = 0.5f * (u[xi][0] + u[xi][1]); o[2 * 64 * 8] = 0.5f * (u[xi][0] - u[xi][1]); o[3 * 64 * 8] = u[xi][1];
-                }
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = xr[k][c], d1 = xr[k][4 + c], d2 = xr[k][8 + c], d3 = xr[k][12 + c];
+                tt_[k][0][c] = d0 - d2; tt_[k][1][c] = d1 + d2; tt_[k][2][c] = d2 - d1; tt_[k][3][c] = d3 - d1;
             }
         }
+        if (sub < 2) {                                           // V = (B^T d) B, rows 2 * sub, + 1
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                const int xi = 2 * sub + x2;
+                const float* t = tt_[k][xi];
+                float* o = buf + ZV + ((xi * 4) * 64 + ch) * 8 + tj;
+                o[0] = t[0] - t[2]; o[64 * 8] = t[1] + t[2]; o[2 * 64 * 8] = t[2] - t[1]; o[3 * 64 * 8] = t[3] - t[1];
+            }
+        } else {                                                 // Z = G e G^T, rows 2 * (sub - 2), + 1
+            const float e00 = dr[k][0].x, e01 = dr[k][0].y, e10 = dr[k][1].x, e11 = dr[k][1].y;
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                const int xi = 2 * (sub - 2) + x2;
+                const float u0 = xi == 0 ? e00 : (xi == 1 ? 0.5f * (e00 + e10) : (xi == 2 ? 0.5f * (e00 - e10) : e10));
+                const float u1 = xi == 0 ? e01 : (xi == 1 ? 0.5f * (e01 + e11) : (xi == 2 ? 0.5f * (e01 - e11) : e11));
+                float* o = buf + ((xi * 4) * 64 + ch) * 8 + tj;
+                o[0] = u0; o[64 * 8] = 0.5f * (u0 + u1); o[2 * 64 * 8] = 0.5f * (u0 - u1); o[3 * 64 * 8] = u1;
+            }
+        }
+    };
+    auto transform_store = [&](float* buf) {
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) transform_piece(buf, tp);
     };
 
     f32x16 acc[16];
@@ -385,8 +401,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float
                     zf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + zl);
                     vf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + vl);
                 }
-                if (pos == 1 && o + 1 < o_end) transform_store(nxt);
-                if (pos == 3) load_oct(o + 2);                  // (past the range: zero range, nothing is fetched)
+                if (pos >= 1 && pos <= 8 && o + 1 < o_end) transform_piece(nxt, pos - 1);
+                if (pos >= 9 && pos <= 12) load_piece(o + 2, pos - 9);      // (past the range: zero range, nothing is fetched)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zf[pos & 1][j]), __uint_as_float(vf[pos & 1][j]), acc[pos], 0, 0, 0);
