@@ -270,6 +270,194 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// conv4x4 stride 2 pad 1 (the discriminators' down-sampling convs), forward: polyphase + Winograd F(2x2, 2x2).
+//     out[oy][ox] = sum_{r,s} w[r][s] x[2 oy + r - 1][2 ox + s - 1]:  the odd input rows O[i] = x[2i + 1] see the taps r = 0, 2 (at O[oy - 1],
+//     O[oy]), the even rows E[i] = x[2i] the taps r = 1, 3 (at E[oy], E[oy + 1]) -- per dimension two 2-tap stride-1 filters on the two
+//     phase images, in 2-D four phases (p, q) of 2x2 taps.  Each is F(2x2, 2x2): 2x2 outputs from a 3x3 phase patch with 9 products
+//     instead of 16:   B^T = [[1,-1,0],[0,1,0],[0,-1,1]],  G = [[1,0],[1,1],[0,1]],  A^T = [[1,1,0],[0,1,1]]  (all +-1: exact transforms
+//     up to the adds).  The output transform is the same for the four phases, so their products are summed in the SAME nine
+//     accumulators: 36 products per 2x2 outputs and input channel instead of 64.
+// Structure as conv_wino_f32_kernel: 32 tiles x 128 output channels per workgroup, a wave = one cout fragment x all 9 positions (144
+// accumulator registers), input channels 8 at a time = 36 stages (phase, position) of 4 MFMAs; the raw patch of a tile is 6 x 6 pixels
+// (rows / columns 4 t .. 4 t + 5 of the block's patch), a phase takes every second row / column of it.
+template <int NFW>
+__global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ out,
+                                                                  const Geom g, const WinoPlan wp) {
+    constexpr int NTG = 4 / NFW, NTL = 32 * NTG, LT = NTG == 1 ? 5 : 6;
+    constexpr int NI = NTG == 1 ? 21 : 36;                         // raw staging values per thread and chunk
+    constexpr int NP = 36;                                         // (phase, position) planes
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fw = w % NFW, tg = w / NFW;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int mt, nt;
+    {
+        const int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles);
+        nt = F % wp.ntiles; mt = F / wp.ntiles;
+    }
+    const int n0 = nt * (NFW * 32);
+    const int txl = wp.txl, tyl = wp.tyl;
+    const int TX = 1 << txl, TY = 1 << tyl;
+    const int bxi = mt % wp.blocks_x, byi = (mt / wp.blocks_x) % wp.blocks_y, bbi = mt / (wp.blocks_x * wp.blocks_y);
+    const int tx0 = bxi << txl, ty0 = byi << tyl, tb0 = bbi << (LT - txl - tyl);
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const int PR = 4 * TY + 2, PC = 4 * TX + 2;                     // raw patch rows / columns per image
+    const int PCP = wp.pcp;
+    float* const raw = reinterpret_cast<float*>(lds);                               // [2 buffers][tb][8 ci][PR][PCP]
+    const int RAWBUF = wp.raw_bytes >> 2;
+    float* const V = reinterpret_cast<float*>(lds + 2 * wp.raw_bytes);              // [2 buffers][36 planes][NTL tiles][8 ci]
+    constexpr int VBUF = NP * NTL * 8;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(U, (size_t)NP * (g.Cin >> 3) * g.Nld * 8 * sizeof(float));
+    const int nch = g.Cin >> 3;
+
+    unsigned it_lds[NI];
+    int it_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int col = e % PC, t1 = e / PC;
+        const int row = t1 % PR, t2 = t1 / PR;
+        const int ci = t2 & 7, tb = t2 >> 3;
+        const int b = tb0 + tb, iy = 4 * ty0 - 1 + row, ix = 4 * tx0 - 1 + col;
+        const bool ok = (e < wp.raw_items) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+        it_off[i] = ok ? (b * g.Cin + ci) * ihw + iy * g.IW + ix : -1;
+        it_lds[i] = (unsigned)(((tb * 8 + ci) * PR + row) * PCP + col);
+    }
+    float rawv[NI];
+    auto load_raw = [&](int ch, float (&rv)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
+    };
+    auto store_raw = [&](int ch, const float (&rv)[NI]) {
+        float* const rb = raw + (ch & 1) * RAWBUF;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tid + i * 256 < wp.raw_items) rb[it_lds[i]] = rv[i];
+    };
+    // input transform, one (tile group k, phase) piece at a time: thread (tile (tid >> 3) + 32 k, channel tid & 7)
+    const int tci = tid & 7;
+    auto transform_piece = [&](const float* rb, float* Vb, int pi) {
+        const int k = pi >> 2, ph = pi & 3, p = ph >> 1, q = ph & 1;
+        const int tt = (tid >> 3) + 32 * k;
+        const int ttx = tt & (TX - 1), tty = (tt >> txl) & (TY - 1), ttb = tt >> (txl + tyl);
+        const float* const src = rb + ((ttb * 8 + tci) * PR + 4 * tty + p) * PCP + 4 * ttx + q;
+        float t[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float d0 = src[2 * j], d1 = src[2 * PCP + 2 * j], d2 = src[4 * PCP + 2 * j];
+            t[0][j] = d0 - d1; t[1][j] = d1; t[2][j] = d2 - d1;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 3; ++xi) {
+            float* o = Vb + ((ph * 9 + xi * 3) * NTL + tt) * 8 + tci;
+            o[0] = t[xi][0] - t[xi][1]; o[NTL * 8] = t[xi][1]; o[2 * NTL * 8] = t[xi][2] - t[xi][1];
+        }
+    };
+    const unsigned ulane = (unsigned)(min(n0 + fw * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    auto load_u = [&](int ch, int half, u32x4 (&uf)[18]) {           // planes 18 * half ..
+#pragma unroll
+        for (int q = 0; q < 18; ++q)
+            uf[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rU, ulane, (unsigned)(((half * 18 + q) * nch + min(ch, nch - 1)) * g.Nld) * 32u, 0));
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ua[18], ub[18];
+    {
+        load_raw(0, rawv);
+        load_u(0, 0, ua);
+        store_raw(0, rawv);
+        if (nch > 1) load_raw(1, rawv);
+        lds_barrier_w();
+#pragma unroll
+        for (int pi = 0; pi < 4 * NTG; ++pi) transform_piece(raw, V, pi);
+        if (nch > 1) store_raw(1, rawv);
+        lds_barrier_w();
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Vc = V + (ch & 1) * VBUF;
+        float* Vn = V + ((ch + 1) & 1) * VBUF;
+        const float* rn = raw + ((ch + 1) & 1) * RAWBUF;
+        const bool more = ch + 1 < nch;
+        const unsigned vlane = (unsigned)((tg * 32 + l31) * 8 + lh * 4);
+        u32x4 vf[2];
+        vf[0] = *reinterpret_cast<const u32x4*>(Vc + vlane);
+#pragma unroll
+        for (int st = 0; st < NP; ++st) {
+            if (st + 1 < NP) vf[(st + 1) & 1] = *reinterpret_cast<const u32x4*>(Vc + (st + 1) * NTL * 8 + vlane);
+            if (st == 0) load_u(ch, 1, ub);
+            if (st == 1 && ch + 2 < nch) load_raw(ch + 2, rawv);
+            if (st == 18) load_u(ch + 1, 0, ua);
+            if (more && st >= 2 && st < 2 + 4 * NTG) transform_piece(rn, Vn, st - 2);
+            if (st == 32 && ch + 2 < nch) store_raw(ch + 2, rawv);
+            const u32x4 uf = st < 18 ? ua[st % 18] : ub[st % 18];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[st % 9] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[j]), __uint_as_float(vf[st & 1][j]), acc[st % 9], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier_w();
+    }
+
+    // ---- output transform in registers: Y = A^T M A, M[xi][nu] = acc[xi * 3 + nu], A^T = [[1, 1, 0], [0, 1, 1]] ----
+    const int lt = tg * 32 + l31;
+    const int tx = lt & (TX - 1), ty = (lt >> txl) & (TY - 1), tb = lt >> (txl + tyl);
+    const int b = tb0 + tb, oy = 2 * (ty0 + ty), ox = 2 * (tx0 + tx);
+    const bool pvalid = (b < g.B) & (oy < g.OH) & (ox < g.OW);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int nw = n0 + fw * 32;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0[3], c1[3];
+#pragma unroll
+        for (int nu = 0; nu < 3; ++nu) {
+            c0[nu] = acc[nu][r] + acc[3 + nu][r];
+            c1[nu] = acc[3 + nu][r] + acc[6 + nu][r];
+        }
+        const int n = nw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = pvalid & (n < g.Cout);
+        const unsigned off = (unsigned)((b * g.Cout + n) * ohw + oy * g.OW + ox) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{c0[0] + c0[1], c0[1] + c0[2]}), ro, ok ? off : kOOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{c1[0] + c1[1], c1[1] + c1[2]}), ro, ok ? off + (unsigned)g.OW * 4u : kOOB, 0, 0);
+    }
+}
+
+// U[(p * 2 + q) * 9 + xi * 3 + nu][ch8][n][8] = (G g_pq G^T)[xi][nu],  g_pq[a][b] = packed[(c, r = 2a + p, s = 2b + q)][n]
+__global__ __launch_bounds__(256) void wino_s2_weight_transform_kernel(const float* __restrict__ wk, float* __restrict__ U, int Kin, int Nld, int N) {
+    const int total = Kin * Nld, nch8 = Kin >> 3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int n = e % Nld, c = e / Nld;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float gk[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) gk[a][b] = n < N ? wk[(size_t)(c * 16 + (2 * a + p) * 4 + 2 * b + q) * Nld + n] : 0.f;
+                const float t[3][2] = {{gk[0][0], gk[0][1]}, {gk[0][0] + gk[1][0], gk[0][1] + gk[1][1]}, {gk[1][0], gk[1][1]}};
+#pragma unroll
+                for (int xi = 0; xi < 3; ++xi) {
+                    const float u[3] = {t[xi][0], t[xi][0] + t[xi][1], t[xi][1]};
+#pragma unroll
+                    for (int nu = 0; nu < 3; ++nu)
+                        U[((size_t)(((p * 2 + q) * 9 + xi * 3 + nu) * nch8 + (c >> 3)) * Nld + n) * 8 + (c & 7)] = u[nu];
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same layers, Winograd F(3x3, 2x2):  dw[r][s] = sum over 2x2 dy tiles e  of  corr(d, e)[r][s],  d = the tile's
 // 4x4 x patch:   dw = A^T [ sum_tiles (G e G^T) (.) (B^T d B) ] A     A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]],
 //                G = [[1,0],[.5,.5],[.5,-.5],[0,1]],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]]      (16 products per tile instead of 36).
@@ -455,8 +643,12 @@ WinoPlan plan_wino(const Geom& g) {
     memset(&p, 0, sizeof(p));
     static const bool off = getenv("AGAN_WINO_OFF") != nullptr;
     if (off) return p;
-    if (!(g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1)) return p;
-    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 1) || (g.Cin & 7) || g.Cout < 32) return p;
+    static const bool s2off = getenv("AGAN_WINO_S2_OFF") != nullptr;
+    if (g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1 && g.IH == g.OH && g.IW == g.OW) p.s2 = 0;
+    else if (!s2off && g.SY == 2 && g.R == 4 && g.S == 4 && g.DY == 1 && g.OS == 1 && g.OY0 == -1 && g.IH == 2 * g.OH && g.IW == 2 * g.OW) p.s2 = 1;
+    else return p;
+    if ((g.OH & 1) || (g.OW & 1) || (g.Cin & 7) || g.Cout < 32) return p;
+    if (p.s2 && g.Cout < 96) return p;                        // (the stride-2 kernel is built for 128-channel tiles)
     const int tw = g.OW / 2, th = g.OH / 2;                   // tiles per row / column
     if (tw < 4) return p;                                     // (4x4 maps: two tiles per row -- the direct kernel's K split serves them better)
     p.nf = g.Cout >= 96 ? 4 : 2;                             // cout fragments per workgroup; 4: 32 tiles, 2: 64 tiles
@@ -470,14 +662,16 @@ WinoPlan plan_wino(const Geom& g) {
     p.mtiles = p.blocks_x * p.blocks_y * p.blocks_b;
     p.ntiles = cdiv(g.Cout, p.nf * 32);
     // the 32 x 32 x 2 product needs thousands of tiles to pay for a workgroup's 256 accumulators: small layers stay on the direct kernel
-    if (p.mtiles * p.ntiles < 256) return p;
-    const int PR = 2 * TY + 2, PC = 2 * TX + 2;
+    if (p.mtiles * p.ntiles < (p.s2 ? 512 : 256)) return p;      // (stride 2, measured: 384 workgroups = 1.5 rounds of the chip gain nothing, 768+ do)
+    const int PR = (p.s2 ? 4 : 2) * TY + 2, PC = (p.s2 ? 4 : 2) * TX + 2;
     p.pcp = (PC + 1) & ~1;
     p.raw_items = TB * 8 * PR * PC;
-    if (p.raw_items > (p.nf == 4 ? 7 : 11) * 256) return p;
+    if (p.raw_items > (p.s2 ? 21 : (p.nf == 4 ? 7 : 11)) * 256) return p;
     p.raw_bytes = (TB * 8 * PR * p.pcp * 4 + 15) & ~15;
-    p.smem_bytes = 2 * p.raw_bytes + 2 * 16 * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
-    p.u_bytes = (size_t)16 * (g.Cin / 8) * g.Nld * 8 * sizeof(float);
+    const int planes = p.s2 ? 36 : 16;
+    p.smem_bytes = 2 * p.raw_bytes + 2 * planes * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
+    if (p.smem_bytes > 160 * 1024) return p;
+    p.u_bytes = (size_t)planes * (g.Cin / 8) * g.Nld * 8 * sizeof(float);
     p.ok = 1;
     return p;
 }
@@ -486,8 +680,15 @@ WinoPlan plan_wino(const Geom& g) {
 void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st) {
     float* U = static_cast<float*>(ws);
     const int total = g.Cin * g.Nld;
-    hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
     dim3 grid(p.mtiles * p.ntiles);
+    if (p.s2) {
+        hipLaunchKernelGGL(wino_s2_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+        static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_s2_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)a4;
+        hipLaunchKernelGGL(conv_wino_s2_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        return;
+    }
+    hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
     if (p.nf == 4) {
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
