@@ -899,7 +899,7 @@ size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(gg)) return 0;
     if (prec == AGAN_PREC_F32) {
         const WinoPlan wp = plan_wino(gg);
-        if (wp.ok) return std::max(wp.u_bytes, plan_gather(gg, prec).ws_bytes);      // (a call with a bias / activation epilogue takes the direct kernel)
+        if (wp.ok) return std::max(wp.ws_bytes, plan_gather(gg, prec).ws_bytes);      // (a call with a bias / activation epilogue takes the direct kernel)
     }
     if (prec != AGAN_PREC_F32) {
         size_t a = plan_patch_gather(gg, make_patch_plan(gg)).ws_bytes;
@@ -1032,14 +1032,22 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
         // conv3x3 stride 1 (forward or data gradient) on enough pixels: Winograd F(2x2, 3x3), 2.25x fewer fp32 MFMAs (conv_wino.hip)
         const WinoPlan wp = plan_wino(g);
         if (wp.ok) {
-            if (wp.u_bytes > ws_bytes || !ws) {
-                set_error("conv_gather: workspace %zu < %zu", ws_bytes, wp.u_bytes);
+            if (wp.ws_bytes > ws_bytes || !ws) {
+                set_error("conv_gather: workspace %zu < %zu", ws_bytes, wp.ws_bytes);
                 return AGAN_EWORKSPACE;
             }
             timer_begin(st);
             launch_wino(in, wk, out, g, wp, ws, st);
             timer_end(st);
-            return check_launch("conv_gather/winograd");
+            if (int e = check_launch("conv_gather/winograd")) return e;
+            if (wp.ksplit > 1) {
+                const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
+                hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st,
+                                   reinterpret_cast<const float*>(static_cast<const char*>(ws) + wp.u_bytes), wp.ksplit, n, wp.slab, (const float*)nullptr,
+                                   g.Cout, g.OH * g.OW, out, 0, AGAN_ACT_NONE, (const void*)nullptr, (float*)nullptr);
+                return check_launch("conv_gather/winograd/sum_slabs");
+            }
+            return AGAN_OK;
         }
     }
     if (prec == AGAN_PREC_F32 && small_n_gather_supported(g)) {

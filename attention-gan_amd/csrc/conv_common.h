@@ -322,7 +322,8 @@ struct WinoPlan {
     int nf, ntiles;                     // cout fragments per workgroup (4: 128 channels, 2: 64), cout tiles
     int pcp, raw_items, raw_bytes;      // raw patch: row pitch (floats), values per 8-channel chunk, LDS bytes
     int smem_bytes;
-    size_t u_bytes;                     // transformed weights [16][Cin / 8][Nld][8] fp32: the call's workspace
+    int ksplit, chunks_per_split;       // stride 2: input-channel split of layers that would fill the chip 1.5 times
+    size_t u_bytes, slab, ws_bytes;     // transformed weights [planes][Cin / 8][Nld][8] fp32 at the head of the workspace; partial-sum slabs behind it
 };
 struct WinoWgradPlan {
     int ok, noct, jtiles, itiles, psplit, octs_per_split, smem_bytes;      // tile octets; 64-channel tiles; pixel split

@@ -291,10 +291,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fw = w % NFW, tg = w / NFW;
     const int l31 = lane & 31, lh = lane >> 5;
-    int mt, nt;
+    int mt, nt, ks;
     {
-        const int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles);
-        nt = F % wp.ntiles; mt = F / wp.ntiles;
+        int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles * wp.ksplit);
+        nt = F % wp.ntiles; F /= wp.ntiles;
+        mt = F % wp.mtiles; ks = F / wp.mtiles;                     // ks: which part of the input channels (partial sums to slab ks)
     }
     const int n0 = nt * (NFW * 32);
     const int txl = wp.txl, tyl = wp.tyl;
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
     constexpr int VBUF = NP * NTL * 8;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
     const __amdgpu_buffer_rsrc_t rU = make_rsrc(U, (size_t)NP * (g.Cin >> 3) * g.Nld * 8 * sizeof(float));
-    const int nch = g.Cin >> 3;
+    const int nch_all = g.Cin >> 3;
+    const int c_beg = ks * wp.chunks_per_split, nch = min(nch_all, c_beg + wp.chunks_per_split) - c_beg;      // this workgroup's chunks: c_beg .. c_beg + nch
 
     unsigned it_lds[NI];
     int it_off[NI];
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
     auto load_raw = [&](int ch, float (&rv)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
+            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)((c_beg + ch) * 8 * ihw) * 4u);
     };
     auto store_raw = [&](int ch, const float (&rv)[NI]) {
         float* const rb = raw + (ch & 1) * RAWBUF;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
 #pragma unroll
         for (int q = 0; q < 18; ++q)
             uf[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rU, ulane, (unsigned)(((half * 18 + q) * nch + min(ch, nch - 1)) * g.Nld) * 32u, 0));
+                rU, ulane, (unsigned)(((half * 18 + q) * nch_all + c_beg + min(ch, nch - 1)) * g.Nld) * 32u, 0));
     };
 
     f32x16 acc[9];
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
     const int tx = lt & (TX - 1), ty = (lt >> txl) & (TY - 1), tb = lt >> (txl + tyl);
     const int b = tb0 + tb, oy = 2 * (ty0 + ty), ox = 2 * (tx0 + tx);
     const bool pvalid = (b < g.B) & (oy < g.OH) & (ox < g.OW);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)ks * wp.slab, (size_t)g.B * g.Cout * ohw * sizeof(float));
     const int nw = n0 + fw * 32;
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -662,7 +664,13 @@ WinoPlan plan_wino(const Geom& g) {
     p.mtiles = p.blocks_x * p.blocks_y * p.blocks_b;
     p.ntiles = cdiv(g.Cout, p.nf * 32);
     // the 32 x 32 x 2 product needs thousands of tiles to pay for a workgroup's 256 accumulators: small layers stay on the direct kernel
-    if (p.mtiles * p.ntiles < (p.s2 ? 512 : 256)) return p;      // (stride 2, measured: 384 workgroups = 1.5 rounds of the chip gain nothing, 768+ do)
+    // (stride 2, measured: 384 workgroups = 1.5 rounds of the chip gain nothing, 768+ do: such layers split their input channels over two
+    //  workgroups and sum the halves -- their outputs are small)
+    p.ksplit = 1;
+    if (p.s2 && p.mtiles * p.ntiles < 512 && p.mtiles * p.ntiles >= 256 && g.Cin >= 128) p.ksplit = 2;
+    if (p.mtiles * p.ntiles * p.ksplit < (p.s2 ? 512 : 256)) return p;
+    p.chunks_per_split = cdiv(g.Cin / 8, p.ksplit);
+    p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
     const int PR = (p.s2 ? 4 : 2) * TY + 2, PC = (p.s2 ? 4 : 2) * TX + 2;
     p.pcp = (PC + 1) & ~1;
     p.raw_items = TB * 8 * PR * PC;
@@ -671,7 +679,8 @@ WinoPlan plan_wino(const Geom& g) {
     const int planes = p.s2 ? 36 : 16;
     p.smem_bytes = 2 * p.raw_bytes + 2 * planes * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
     if (p.smem_bytes > 160 * 1024) return p;
-    p.u_bytes = (size_t)planes * (g.Cin / 8) * g.Nld * 8 * sizeof(float);
+    p.u_bytes = ((size_t)planes * (g.Cin / 8) * g.Nld * 8 * sizeof(float) + 255) / 256 * 256;
+    p.ws_bytes = p.u_bytes + (p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0);
     p.ok = 1;
     return p;
 }
@@ -680,12 +689,14 @@ WinoPlan plan_wino(const Geom& g) {
 void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st) {
     float* U = static_cast<float*>(ws);
     const int total = g.Cin * g.Nld;
-    dim3 grid(p.mtiles * p.ntiles);
+    dim3 grid(p.mtiles * p.ntiles * p.ksplit);
     if (p.s2) {
         hipLaunchKernelGGL(wino_s2_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_s2_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
-        hipLaunchKernelGGL(conv_wino_s2_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        // (a split launch writes its partial sums to the slabs behind U in the workspace: the caller sums them into `out`)
+        float* dst = p.ksplit > 1 ? reinterpret_cast<float*>(static_cast<char*>(ws) + p.u_bytes) : out;
+        hipLaunchKernelGGL(conv_wino_s2_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, dst, g, p);
         return;
     }
     hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
