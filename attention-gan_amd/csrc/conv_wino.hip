@@ -433,6 +433,186 @@ __global__ __launch_bounds__(256, 1) void conv_wino_s2_f32_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Data gradient of conv4x4 stride 2: four parity classes of the output, each a 2x2-tap stride-1 gather over dy with taps running backwards
+// (include/agan.h: DY = -1, offsets (0, 1)).  Per class Winograd F(2x2, 2x2) on the class lattice: 9 products per 2x2 lattice points instead of
+// 16.  out[2 yq + py][2 xq + px] = sum_{r,s} Wc[r][s] dy[yq + py - r][xq + px - s] = correlation of the ascending window
+// (dy[yq + py - 1], dy[yq + py]) with g = (Wc[1], Wc[0]).  Same structure as the kernels above; a channel chunk is 16 channels = 18 stages
+// (position, 8-channel half) of 4 MFMAs; the four classes are grid entries; the 2x2 outputs of a tile lie two pixels apart (scalar stores).
+template <int NFW>
+__global__ __launch_bounds__(256, 1) void conv_wino_cls_f32_kernel(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ out,
+                                                                   const Geom g, const WinoPlan wp) {
+    constexpr int NTG = 4 / NFW, NTL = 32 * NTG, LT = NTG == 1 ? 5 : 6;
+    constexpr int NI = NTG == 1 ? 11 : 19;                         // raw staging values per thread and chunk (16 channels)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fw = w % NFW, tg = w / NFW;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int mt, nt, cls;
+    {
+        int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles * 4);
+        nt = F % wp.ntiles; F /= wp.ntiles;
+        cls = F & 3; mt = F >> 2;                                   // (the four classes of a block read the same dy patch: neighbours)
+    }
+    const int py = cls >> 1, px = cls & 1;
+    const int n0 = nt * (NFW * 32);
+    const int txl = wp.txl, tyl = wp.tyl;
+    const int TX = 1 << txl, TY = 1 << tyl;
+    const int bxi = mt % wp.blocks_x, byi = (mt / wp.blocks_x) % wp.blocks_y, bbi = mt / (wp.blocks_x * wp.blocks_y);
+    const int tx0 = bxi << txl, ty0 = byi << tyl, tb0 = bbi << (LT - txl - tyl);
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const int PR = 2 * TY + 1, PC = 2 * TX + 1;
+    const int PCP = wp.pcp;
+    float* const raw = reinterpret_cast<float*>(lds);                               // [2 buffers][tb][16 ci][PR][PCP]
+    const int RAWBUF = wp.raw_bytes >> 2;
+    float* const V = reinterpret_cast<float*>(lds + 2 * wp.raw_bytes);              // [2 buffers][9 positions][NTL tiles][16 ci]
+    constexpr int VBUF = 9 * NTL * 16;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const int nch8 = g.Cin >> 3, nch = g.Cin >> 4;
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(U + (size_t)cls * 9 * nch8 * g.Nld * 8, (size_t)9 * nch8 * g.Nld * 8 * sizeof(float));
+
+    unsigned it_lds[NI];
+    int it_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int col = e % PC, t1 = e / PC;
+        const int row = t1 % PR, t2 = t1 / PR;
+        const int ci = t2 & 15, tb = t2 >> 4;
+        const int b = tb0 + tb, iy = 2 * ty0 + py - 1 + row, ix = 2 * tx0 + px - 1 + col;
+        const bool ok = (e < wp.raw_items) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+        it_off[i] = ok ? (b * g.Cin + ci) * ihw + iy * g.IW + ix : -1;
+        it_lds[i] = (unsigned)(((tb * 16 + ci) * PR + row) * PCP + col);
+    }
+    float rawv[NI];
+    auto load_raw = [&](int ch, float (&rv)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 16 * ihw) * 4u);
+    };
+    auto store_raw = [&](int ch, const float (&rv)[NI]) {
+        float* const rb = raw + (ch & 1) * RAWBUF;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tid + i * 256 < wp.raw_items) rb[it_lds[i]] = rv[i];
+    };
+    // input transform, one (tile, channel) pair per piece: pair pi of this thread = (tile (tid >> 3) + 32 (pi >> 1), channel (tid & 7) + 8 (pi & 1))
+    auto transform_piece = [&](const float* rb, float* Vb, int pi) {
+        const int tt = (tid >> 3) + 32 * (pi >> 1), ci = (tid & 7) + 8 * (pi & 1);
+        const int ttx = tt & (TX - 1), tty = (tt >> txl) & (TY - 1), ttb = tt >> (txl + tyl);
+        const float* const src = rb + ((ttb * 16 + ci) * PR + 2 * tty) * PCP + 2 * ttx;
+        float t[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float d0 = src[j], d1 = src[PCP + j], d2 = src[2 * PCP + j];
+            t[0][j] = d0 - d1; t[1][j] = d1; t[2][j] = d2 - d1;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 3; ++xi) {
+            float* o = Vb + ((xi * 3) * NTL + tt) * 16 + ci;
+            o[0] = t[xi][0] - t[xi][1]; o[NTL * 16] = t[xi][1]; o[2 * NTL * 16] = t[xi][2] - t[xi][1];
+        }
+    };
+    const unsigned ulane = (unsigned)(min(n0 + fw * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    auto load_u = [&](int ch, int half, u32x4 (&uf)[9]) {           // stages 9 * half ..: stage = position * 2 + 8-channel half
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int st = half * 9 + q;
+            uf[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rU, ulane, (unsigned)(((st >> 1) * nch8 + 2 * min(ch, nch - 1) + (st & 1)) * g.Nld) * 32u, 0));
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ua[9], ub[9];
+    {
+        load_raw(0, rawv);
+        load_u(0, 0, ua);
+        store_raw(0, rawv);
+        if (nch > 1) load_raw(1, rawv);
+        lds_barrier_w();
+#pragma unroll
+        for (int pi = 0; pi < 2 * NTG; ++pi) transform_piece(raw, V, pi);
+        if (nch > 1) store_raw(1, rawv);
+        lds_barrier_w();
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Vc = V + (ch & 1) * VBUF;
+        float* Vn = V + ((ch + 1) & 1) * VBUF;
+        const float* rn = raw + ((ch + 1) & 1) * RAWBUF;
+        const bool more = ch + 1 < nch;
+        const unsigned vlane = (unsigned)((tg * 32 + l31) * 16 + lh * 4);
+        u32x4 vf[2];
+        vf[0] = *reinterpret_cast<const u32x4*>(Vc + vlane);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) vf[(st + 1) & 1] = *reinterpret_cast<const u32x4*>(Vc + ((st + 1) >> 1) * NTL * 16 + ((st + 1) & 1) * 8 + vlane);
+            if (st == 0) load_u(ch, 1, ub);
+            if (st == 1 && ch + 2 < nch) load_raw(ch + 2, rawv);
+            if (st == 9) load_u(ch + 1, 0, ua);
+            if (more && st >= 2 && st < 2 + 2 * NTG) transform_piece(rn, Vn, st - 2);
+            if (st == 15 && ch + 2 < nch) store_raw(ch + 2, rawv);
+            const u32x4 uf = st < 9 ? ua[st % 9] : ub[st % 9];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[st >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[j]), __uint_as_float(vf[st & 1][j]), acc[st >> 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier_w();
+    }
+
+    // ---- output transform in registers: Y = A^T M A, A^T = [[1, 1, 0], [0, 1, 1]]; lattice point (yq, xq) -> pixel (2 yq + py, 2 xq + px) ----
+    const int lt = tg * 32 + l31;
+    const int tx = lt & (TX - 1), ty = (lt >> txl) & (TY - 1), tb = lt >> (txl + tyl);
+    const int b = tb0 + tb, yq = 2 * (ty0 + ty), xq = 2 * (tx0 + tx);
+    const bool pvalid = (b < g.B) & (yq < g.OHs) & (xq < g.OWs);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int nw = n0 + fw * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0[3], c1[3];
+#pragma unroll
+        for (int nu = 0; nu < 3; ++nu) {
+            c0[nu] = acc[nu][r] + acc[3 + nu][r];
+            c1[nu] = acc[3 + nu][r] + acc[6 + nu][r];
+        }
+        const int n = nw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = pvalid & (n < g.Cout);
+        const unsigned off = (unsigned)((b * g.Cout + n) * ohw + (2 * yq + py) * g.OW + 2 * xq + px) * 4u;
+        buf_store(ro, ok ? off : kOOB, c0[0] + c0[1]);
+        buf_store(ro, ok ? off + 8u : kOOB, c0[1] + c0[2]);
+        buf_store(ro, ok ? off + (unsigned)(2 * g.OW) * 4u : kOOB, c1[0] + c1[1]);
+        buf_store(ro, ok ? off + (unsigned)(2 * g.OW + 2) * 4u : kOOB, c1[1] + c1[2]);
+    }
+}
+
+// U[cls][xi * 3 + nu][ch8][n][8] = (G g G^T)[xi][nu],  g[a][b] = packed_cls[(c, r = 1 - a, s = 1 - b)][n]   (taps run backwards: DY = -1)
+__global__ __launch_bounds__(256) void wino_cls_weight_transform_kernel(const float* __restrict__ wk, float* __restrict__ U, int Kin, int Nld, int N) {
+    const int total = 4 * Kin * Nld, nch8 = Kin >> 3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int n = e % Nld, t1 = e / Nld, c = t1 % Kin, cls = t1 / Kin;
+        const float* wc = wk + (size_t)cls * Kin * 4 * Nld;
+        float gk[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) gk[a][b] = n < N ? wc[(size_t)(c * 4 + (1 - a) * 2 + (1 - b)) * Nld + n] : 0.f;
+        const float t[3][2] = {{gk[0][0], gk[0][1]}, {gk[0][0] + gk[1][0], gk[0][1] + gk[1][1]}, {gk[1][0], gk[1][1]}};
+#pragma unroll
+        for (int xi = 0; xi < 3; ++xi) {
+            const float u[3] = {t[xi][0], t[xi][0] + t[xi][1], t[xi][1]};
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu)
+                U[((size_t)((cls * 9 + xi * 3 + nu) * nch8 + (c >> 3)) * Nld + n) * 8 + (c & 7)] = u[nu];
+        }
+    }
+}
+
 // U[(p * 2 + q) * 9 + xi * 3 + nu][ch8][n][8] = (G g_pq G^T)[xi][nu],  g_pq[a][b] = packed[(c, r = 2a + p, s = 2b + q)][n]
 __global__ __launch_bounds__(256) void wino_s2_weight_transform_kernel(const float* __restrict__ wk, float* __restrict__ U, int Kin, int Nld, int N) {
     const int total = Kin * Nld, nch8 = Kin >> 3;
@@ -648,10 +828,14 @@ WinoPlan plan_wino(const Geom& g) {
     static const bool s2off = getenv("AGAN_WINO_S2_OFF") != nullptr;
     if (g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1 && g.IH == g.OH && g.IW == g.OW) p.s2 = 0;
     else if (!s2off && g.SY == 2 && g.R == 4 && g.S == 4 && g.DY == 1 && g.OS == 1 && g.OY0 == -1 && g.IH == 2 * g.OH && g.IW == 2 * g.OW) p.s2 = 1;
+    else if (!s2off && g.SY == 1 && g.R == 2 && g.S == 2 && g.DY == -1 && g.OS == 2 && g.OY0 == 0 && g.OY1 == 1 && g.OH == 2 * g.IH && g.OW == 2 * g.IW) p.s2 = 2;
     else return p;
-    if ((g.OH & 1) || (g.OW & 1) || (g.Cin & 7) || g.Cout < 32) return p;
-    if (p.s2 && g.Cout < 96) return p;                        // (the stride-2 kernel is built for 128-channel tiles)
-    const int tw = g.OW / 2, th = g.OH / 2;                   // tiles per row / column
+    if ((g.OHs & 1) || (g.OWs & 1) || (g.Cin & 7) || g.Cout < 32) return p;
+    if (p.s2 == 1 && g.Cout < 96) return p;                   // (the stride-2 forward kernel is built for 128-channel tiles)
+    // (the class kernel walks 16 channels at a time; with 64 output channels -- 64-tile blocks, short K loops, 64 scalar stores per lane -- it
+    //  measured 15 % SLOWER than the direct kernel, with 128+ 15 % faster)
+    if (p.s2 == 2 && ((g.Cin & 15) || g.Cout < 96)) return p;
+    const int tw = g.OWs / 2, th = g.OHs / 2;                 // tiles per row / column of the output lattice
     if (tw < 4) return p;                                     // (4x4 maps: two tiles per row -- the direct kernel's K split serves them better)
     p.nf = g.Cout >= 96 ? 4 : 2;                             // cout fragments per workgroup; 4: 32 tiles, 2: 64 tiles
     const int lt = p.nf == 4 ? 5 : 6;
@@ -667,17 +851,18 @@ WinoPlan plan_wino(const Geom& g) {
     // (stride 2, measured: 384 workgroups = 1.5 rounds of the chip gain nothing, 768+ do: such layers split their input channels over two
     //  workgroups and sum the halves -- their outputs are small)
     p.ksplit = 1;
-    if (p.s2 && p.mtiles * p.ntiles < 512 && p.mtiles * p.ntiles >= 256 && g.Cin >= 128) p.ksplit = 2;
-    if (p.mtiles * p.ntiles * p.ksplit < (p.s2 ? 512 : 256)) return p;
+    if (p.s2 == 1 && p.mtiles * p.ntiles < 512 && p.mtiles * p.ntiles >= 256 && g.Cin >= 128) p.ksplit = 2;
+    if (p.mtiles * p.ntiles * p.ksplit * (p.s2 == 2 ? 4 : 1) < (p.s2 ? 512 : 256)) return p;
     p.chunks_per_split = cdiv(g.Cin / 8, p.ksplit);
     p.slab = ((size_t)g.B * g.Cout * g.OH * g.OW + 3) / 4 * 4;
-    const int PR = (p.s2 ? 4 : 2) * TY + 2, PC = (p.s2 ? 4 : 2) * TX + 2;
+    const int PR = p.s2 == 2 ? 2 * TY + 1 : (p.s2 ? 4 : 2) * TY + 2, PC = p.s2 == 2 ? 2 * TX + 1 : (p.s2 ? 4 : 2) * TX + 2;
+    const int cch = p.s2 == 2 ? 16 : 8;                       // channels per chunk
     p.pcp = (PC + 1) & ~1;
-    p.raw_items = TB * 8 * PR * PC;
-    if (p.raw_items > (p.s2 ? 21 : (p.nf == 4 ? 7 : 11)) * 256) return p;
-    p.raw_bytes = (TB * 8 * PR * p.pcp * 4 + 15) & ~15;
-    const int planes = p.s2 ? 36 : 16;
-    p.smem_bytes = 2 * p.raw_bytes + 2 * planes * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
+    p.raw_items = TB * cch * PR * PC;
+    if (p.raw_items > (p.s2 == 2 ? (p.nf == 4 ? 11 : 19) : (p.s2 ? 21 : (p.nf == 4 ? 7 : 11))) * 256) return p;
+    p.raw_bytes = (TB * cch * PR * p.pcp * 4 + 15) & ~15;
+    const int planes = p.s2 == 2 ? 9 * 4 : (p.s2 ? 36 : 16);  // (class kernel: 9 positions x 4 classes of weights; its V holds 9 x 16 channels)
+    p.smem_bytes = 2 * p.raw_bytes + 2 * (p.s2 == 2 ? 9 * 2 : planes) * (1 << lt) * 8 * 4;      // two raw patches, two V buffers
     if (p.smem_bytes > 160 * 1024) return p;
     p.u_bytes = ((size_t)planes * (g.Cin / 8) * g.Nld * 8 * sizeof(float) + 255) / 256 * 256;
     p.ws_bytes = p.u_bytes + (p.ksplit > 1 ? p.slab * p.ksplit * sizeof(float) : 0);
@@ -690,6 +875,20 @@ void launch_wino(const float* in, const float* wk, float* out, const Geom& g, co
     float* U = static_cast<float*>(ws);
     const int total = g.Cin * g.Nld;
     dim3 grid(p.mtiles * p.ntiles * p.ksplit);
+    if (p.s2 == 2) {
+        hipLaunchKernelGGL(wino_cls_weight_transform_kernel, dim3(std::min(cdiv(4 * total, 256), 4096)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+        dim3 gridc(p.mtiles * p.ntiles * 4);
+        if (p.nf == 4) {
+            static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cls_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)a4;
+            hipLaunchKernelGGL(conv_wino_cls_f32_kernel<4>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        } else {
+            static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cls_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)a2;
+            hipLaunchKernelGGL(conv_wino_cls_f32_kernel<2>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        }
+        return;
+    }
     if (p.s2) {
         hipLaunchKernelGGL(wino_s2_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_s2_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
