@@ -26,7 +26,7 @@ CASES = [
     ("same", 8, 16, 64, 64, 128, "3x3: 128-channel tiles, 4 x 8 tile blocks"),
     ("same", 4, 24, 128, 128, 64, "3x3: 64-channel tiles of 64 tiles (8 x 8 blocks), weight gradient with an input-channel tail"),
     ("same", 12, 8, 40, 96, 160, "3x3: ragged block rows (20 tile rows / 4), two cout tiles, the second half empty"),
-    ("same", 64, 32, 16, 16, 128, "3x3: 16 x 16 maps: a block spans two images, weight gradient with few octets per image row"),
+    ("same", 64, 32, 16, 16, 128, "3x3: 16 x 16 maps (two 4 x 8 blocks per image); too few tile octets for the Winograd weight gradient -> row-resident kernel"),
     ("down", 16, 16, 128, 128, 128, "4x4 s2 forward: polyphase, 512 workgroups; data gradient: 64 output channels -> direct kernel"),
     ("down", 8, 128, 128, 128, 128, "4x4 s2 forward: 256 workgroups -> input-channel split + slab sum; data gradient: class-wise Winograd"),
     ("down", 16, 128, 64, 64, 32, "4x4 s2: data gradient class-wise Winograd (128 output channels, 16-channel chunks), forward direct (32 channels)"),
