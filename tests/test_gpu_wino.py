@@ -3,8 +3,8 @@
 AGAN_PREC_F32 routes the 3x3 stride-1 layers (forward, data gradient, weight gradient) and the large 4x4 stride-2 layers (forward: polyphase
 F(2x2, 2x2); data gradient: class-wise F(2x2, 2x2)) through Winograd transforms when a layer has enough tiles to fill the chip.  Every case
 below is sized to take one plan path (the comment says which); results must agree with the fp64 reference to a few fp32 ulps of the largest
-entry -- the transforms add a handful of roundings, nothing more.  A final test runs the same layers with AGAN_WINO_OFF-equivalent shapes
-(too few tiles) to make sure the direct kernels still agree with the same reference, i.e. the two families are interchangeable.
+entry -- the transforms add a handful of roundings, nothing more.  (Layers with too few tiles stay on the direct kernels: those are what the
+fixed and random shapes of tests/test_gpu_parity.py exercise, against the same kind of reference.)
 """
 import importlib
 
