@@ -50,6 +50,7 @@ _SIGNATURES = {
     "agan_pack_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "agan_conv_effective_prec": (c_int, [POINTER(ConvGeom), c_int]),
     "agan_conv_wgrad_effective_prec": (c_int, [POINTER(ConvGeom), c_int, c_int]),
+    "agan_conv_executed_fraction": (c_double, [POINTER(ConvGeom), c_int, c_int, c_int]),
     "agan_conv_gather_ws_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
     "agan_conv_ktable_elems": (c_size_t, [POINTER(ConvGeom)]),
     "agan_conv_ktable": (c_int, [POINTER(ConvGeom), _P, _P]),

@@ -892,6 +892,16 @@ int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int p
     return prec;
 }
 
+double agan_conv_executed_fraction(const agan_conv_geom* g, int prec, int wgrad, int plain_epilogue) {
+    if (check_geom(g) || prec != AGAN_PREC_F32) return 1.0;
+    const Geom gg = make_geom(g);
+    if (wgrad) return plan_wino_wgrad(gg).ok ? 16.0 / 36.0 : 1.0;
+    if (!plain_epilogue) return 1.0;
+    const WinoPlan wp = plan_wino(gg);
+    if (!wp.ok) return 1.0;
+    return wp.s2 == 0 ? 16.0 / 36.0 : (wp.s2 == 1 ? 36.0 / 64.0 : 9.0 / 16.0);
+}
+
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec) {
     if (check_geom(g)) return 0;
     const Geom gg = make_geom(g);

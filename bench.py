@@ -70,10 +70,15 @@ class ConvTimer:
         if not self.enabled:
             return
         K = g.Cin * g.R * g.S
-        executed = 2.0 * g.B * g.OH * g.OW * g.Cout * K          # MACs the kernel really issues (x2)
+        executed = 2.0 * g.B * g.OH * g.OW * g.Cout * K          # MACs of the direct contraction (x2) ...
+        direct = executed
         # algorithmic = the REFERENCE's contraction for this call: Upsample+conv3x3 is 9 taps on the 2x grid,
         # the folded kernels (fwd: 4 classes x 2x2 taps; dgrad: 4x4 s2; wgrad: 4 classes) execute 4/9 of that.
-        algorithmic = executed * (9.0 / 4.0) if kind == "up" else executed
+        algorithmic = direct * (9.0 / 4.0) if kind == "up" else direct
+        if self.mode == "f32" and g.Cout > 4:
+            # ... of which the fp32 mode's Winograd kernels issue 16/36 (conv3x3), 36/64 (conv4x4 s2 forward) or 9/16 (its data gradient).
+            # (the conv calls on this path carry no bias / activation epilogue except the first discriminator conv, which has 3 input channels)
+            executed = direct * float(self.lib.load().agan_conv_executed_fraction(ctypes.byref(g), 0, 1 if phase == "wgrad" else 0, 1))
         tile = "n128" if (g.Cout >= 96) else ("n64" if g.Cout >= 48 else "n32")
         if g.Cout <= 4:
             tile = "small_n"

@@ -126,6 +126,11 @@ int agan_conv_effective_prec(const agan_conv_geom* g, int prec);
 /* ... and the one its weight gradient gets (agan_conv_wgrad demotes by itself; a caller needs this to know whether the
  * AGAN_PREC_F16X3 scales are wanted).  g = the FORWARD geometry, pack_mode = AGAN_PACK_FWD or AGAN_PACK_UP_FWD. */
 int agan_conv_wgrad_effective_prec(const agan_conv_geom* g, int pack_mode, int prec);
+/* Fraction of the direct contraction's multiply-adds that the kernel chosen for this call really issues (measurement aid: bench.py's
+ * executed_tflops).  1.0 except where AGAN_PREC_F32 takes a Winograd kernel (csrc/conv_wino.hip): 16/36 for conv3x3 stride 1 (forward,
+ * data gradient, weight gradient), 36/64 for the conv4x4 stride-2 forward, 9/16 for its class-wise data gradient.  wgrad != 0: g is the
+ * FORWARD geometry of a weight gradient; plain_epilogue = 0: the call carries a bias / activation / mask (the Winograd gathers have none). */
+double agan_conv_executed_fraction(const agan_conv_geom* g, int prec, int wgrad, int plain_epilogue);
 size_t agan_conv_gather_ws_bytes(const agan_conv_geom* g, int prec);
 /* lrelu_mask (optional, data-gradient launches): a tensor of the OUTPUT's shape; out is multiplied by LeakyReLU'(mask) = 1 where
  * mask > 0, else 0.2 -- the backward of the LeakyReLU that produced this conv's forward input (the mask is that input), folded

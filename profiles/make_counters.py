@@ -38,11 +38,13 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_gather_patch16 (fwd/dgrad, 16-bit MFMA)", ["conv_patch_kernel"]),
     ("conv_wgrad_rows (row-resident weight gradient, conv_wgrows.hip)", ["conv_wgrad_rows_kernel"]),
     ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
+    ("conv_wino gather (fp32 Winograd: conv3x3 fwd/dgrad, conv4x4-s2 fwd + class-wise dgrad)", ["conv_wino_f32_kernel", "conv_wino_s2_f32_kernel", "conv_wino_cls_f32_kernel"]),
+    ("conv_wino weight gradient (fp32 Winograd F(3x3,2x2))", ["conv_wino_wgrad_f32_kernel"]),
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
     ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
     ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel", "small_strip_kernel"]),
     ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel"]),
-    ("weight packs", ["pack_"]),
+    ("weight packs", ["pack_", "weight_transform_kernel"]),
     ("absmax (f16x3: max|x| of small tensors)", ["absmax_kernel"]),
     ("bn_stats_partial", ["bn_stats_partial"]),
     ("bn_act_fwd (normalise + GLU/LeakyReLU)", ["bn_act_fwd_kernel"]),
@@ -69,8 +71,11 @@ def bench_name(kernel, mode):
     for n in (128, 64, 32):
         if f"conv_gather_f32_kernel<128, {n}" in kernel:
             return f"conv_gather_f32_n{n}"
-    if "conv_wgrad_f32_kernel" in kernel:
+    if "conv_wgrad_f32_kernel" in kernel or "conv_wino_wgrad_f32_kernel" in kernel:
         return "conv_wgrad_f32"
+    for wk in ("conv_wino_f32_kernel<", "conv_wino_s2_f32_kernel<", "conv_wino_cls_f32_kernel<"):
+        if wk in kernel:                      # <NFW>: cout fragments per workgroup = 128 / 64 output channels
+            return "conv_gather_f32_n128" if wk + "4>" in kernel else "conv_gather_f32_n64"
     if "conv_patch_wgrad_kernel" in kernel or "conv_wgrad_rows_kernel" in kernel:
         return f"conv_wgrad_{mode}"
     if "conv_patch_kernel" in kernel:
