@@ -316,7 +316,7 @@ struct RowsPlan {
 };
 // ---- Winograd F(2x2, 3x3) for the fp32 conv3x3 stride-1 gathers (conv_wino.hip) ----------------------------------------------------
 struct WinoPlan {
-    int ok, s2;                         // s2: conv4x4 stride 2 (polyphase F(2x2, 2x2)) instead of conv3x3 stride 1 (F(2x2, 3x3))
+    int ok, s2, hmode;                  // hmode: conv3x3 as 32 tiles x 64 channels, half the positions per wave, two workgroups per CU;  s2: conv4x4 stride 2 (polyphase F(2x2, 2x2)) instead of conv3x3 stride 1 (F(2x2, 3x3))
     int txl, tyl;                       // log2 of the tile block's columns / rows (2x2-output tiles); images per block = 32 >> (txl + tyl)
     int blocks_x, blocks_y, blocks_b, mtiles;
     int nf, ntiles;                     // cout fragments per workgroup (4: 128 channels, 2: 64), cout tiles

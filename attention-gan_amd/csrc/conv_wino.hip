@@ -270,6 +270,184 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same F(2x2, 3x3) gather with TWO workgroups per CU: 32 tiles x 64 output channels per workgroup, a wave = one cout fragment x HALF
+// the positions (rows xi = 2 h, 2 h + 1 of the 4 x 4 product: 128 accumulator registers).  One workgroup per CU left its fixed cost --
+// first loads, last stores, every barrier -- uncovered (~5 us of 26); two co-resident workgroups cover each other's.  The price: every
+// (tile, channel) patch is transformed by both cout halves, and the output transform's row direction crosses the two waves of a cout
+// fragment: each wave reduces its two rows to the partial sums of the two output rows and hands ONE of them to its partner through LDS
+// (32 floats per lane), then finishes the other.
+__global__ __launch_bounds__(256, 2) void conv_wino_h_f32_kernel(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ out,
+                                                                 const Geom g, const WinoPlan wp) {
+    constexpr int NTL = 32, NI = 7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fw = w & 1, hh = w >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int mt, nt;
+    {
+        const int F = xcd_contiguous(linear_block_id(), wp.mtiles * wp.ntiles);
+        nt = F % wp.ntiles; mt = F / wp.ntiles;
+    }
+    const int n0 = nt * 64;
+    const int txl = wp.txl, tyl = wp.tyl;
+    const int TX = 1 << txl, TY = 1 << tyl;
+    const int bxi = mt % wp.blocks_x, byi = (mt / wp.blocks_x) % wp.blocks_y, bbi = mt / (wp.blocks_x * wp.blocks_y);
+    const int tx0 = bxi << txl, ty0 = byi << tyl, tb0 = bbi << (5 - txl - tyl);
+    const int ihw = g.IH * g.IW, ohw = g.OH * g.OW;
+    const int PR = 2 * TY + 2, PC = 2 * TX + 2;
+    const int PCP = wp.pcp;
+    float* const raw = reinterpret_cast<float*>(lds);
+    const int RAWBUF = wp.raw_bytes >> 2;
+    float* const V = reinterpret_cast<float*>(lds + 2 * wp.raw_bytes);
+    constexpr int VBUF = 16 * NTL * 8;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (size_t)g.B * g.Cin * ihw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(U, (size_t)16 * (g.Cin >> 3) * g.Nld * 8 * sizeof(float));
+    const int nch = g.Cin >> 3;
+
+    unsigned it_lds[NI];
+    int it_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int col = e % PC, t1 = e / PC;
+        const int row = t1 % PR, t2 = t1 / PR;
+        const int ci = t2 & 7, tb = t2 >> 3;
+        const int b = tb0 + tb, iy = 2 * ty0 - 1 + row, ix = 2 * tx0 - 1 + col;
+        const bool ok = (e < wp.raw_items) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+        it_off[i] = ok ? (b * g.Cin + ci) * ihw + iy * g.IW + ix : -1;
+        it_lds[i] = (unsigned)(((tb * 8 + ci) * PR + row) * PCP + col);
+    }
+    float rawv[NI];
+    auto load_raw = [&](int ch, float (&rv)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            rv[i] = buf_load_s(rx, it_off[i] >= 0 ? (unsigned)it_off[i] * 4u : kOOB, (unsigned)(ch * 8 * ihw) * 4u);
+    };
+    auto store_raw = [&](int ch, const float (&rv)[NI]) {
+        float* const rb = raw + (ch & 1) * RAWBUF;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tid + i * 256 < wp.raw_items) rb[it_lds[i]] = rv[i];
+    };
+    const int tci = tid & 7, tt = tid >> 3;
+    const int ttx = tt & (TX - 1), tty = (tt >> txl) & (TY - 1), ttb = tt >> (txl + tyl);
+    const int tsrc_off = ((ttb * 8 + tci) * PR + 2 * tty) * PCP + 2 * ttx;
+    float td[4][4];
+    auto transform_piece = [&](const float* rb, float* Vb, int xi) {
+        if (xi == 0) {
+            const float* const tsrc = rb + tsrc_off;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(tsrc + i * PCP), b = *reinterpret_cast<const float2*>(tsrc + i * PCP + 2);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                td[0][j] = d[0][j] - d[2][j];
+                td[1][j] = d[1][j] + d[2][j];
+                td[2][j] = d[2][j] - d[1][j];
+                td[3][j] = d[1][j] - d[3][j];
+            }
+        }
+        Vb[((xi * 4 + 0) * NTL + tt) * 8 + tci] = td[xi][0] - td[xi][2];
+        Vb[((xi * 4 + 1) * NTL + tt) * 8 + tci] = td[xi][1] + td[xi][2];
+        Vb[((xi * 4 + 2) * NTL + tt) * 8 + tci] = td[xi][2] - td[xi][1];
+        Vb[((xi * 4 + 3) * NTL + tt) * 8 + tci] = td[xi][1] - td[xi][3];
+    };
+    const unsigned ulane = (unsigned)(min(n0 + fw * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    auto load_u = [&](int ch, int half, u32x4 (&uf)[4]) {            // this wave's positions hh * 8 + half * 4 ..
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            uf[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rU, ulane, (unsigned)(((hh * 8 + half * 4 + q) * nch + min(ch, nch - 1)) * g.Nld) * 32u, 0));
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ua[4], ub[4];
+    {
+        float rawv1[NI];
+        load_raw(0, rawv);
+        if (nch > 1) load_raw(1, rawv1);
+        load_u(0, 0, ua);
+        store_raw(0, rawv);
+        if (nch > 1) store_raw(1, rawv1);
+        lds_barrier_w();
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) transform_piece(raw, V, xi);
+        lds_barrier_w();
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Vc = V + (ch & 1) * VBUF;
+        float* Vn = V + ((ch + 1) & 1) * VBUF;
+        const float* rn = raw + ((ch + 1) & 1) * RAWBUF;
+        const bool more = ch + 1 < nch;
+        const unsigned vlane = (unsigned)(hh * 8 * NTL * 8 + l31 * 8 + lh * 4);
+        u32x4 vf[2];
+        vf[0] = *reinterpret_cast<const u32x4*>(Vc + vlane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) vf[(q + 1) & 1] = *reinterpret_cast<const u32x4*>(Vc + (q + 1) * NTL * 8 + vlane);
+            if (q == 0) load_u(ch, 1, ub);
+            if (q == 1 && ch + 2 < nch) load_raw(ch + 2, rawv);
+            if (q == 4) load_u(ch + 1, 0, ua);
+            if (more && q >= 1 && q <= 4) transform_piece(rn, Vn, q - 1);
+            if (q == 6 && ch + 2 < nch) store_raw(ch + 2, rawv);
+            const u32x4 uf = q < 4 ? ua[q & 3] : ub[q & 3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(uf[j]), __uint_as_float(vf[q & 1][j]), acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier_w();
+    }
+
+    // ---- output transform: columns in registers, rows across the wave pair (fw, hh = 0 / 1).  acc[x2 * 4 + nu] = M[2 hh + x2][nu].
+    //      hh = 0 holds rows 0, 1: output row 0 gets M0 + M1, row 1 gets M1;   hh = 1 holds rows 2, 3: row 0 gets M2, row 1 gets -M2 - M3.
+    //      Wave hh finishes output row hh and sends its contribution to the other row to its partner. ----
+    float* const X = reinterpret_cast<float*>(lds);            // [wave 4][32 values][64 lanes]
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float t[2][2];                                           // [x2][output column]
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) {
+            const float m0 = acc[x2 * 4 + 0][r], m1 = acc[x2 * 4 + 1][r], m2 = acc[x2 * 4 + 2][r], m3 = acc[x2 * 4 + 3][r];
+            t[x2][0] = m0 + m1 + m2;
+            t[x2][1] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float row0 = hh == 0 ? t[0][b] + t[1][b] : t[0][b];
+            const float row1 = hh == 0 ? t[1][b] : -t[0][b] - t[1][b];
+            keep[r][b] = hh == 0 ? row0 : row1;
+            X[(w * 32 + r * 2 + b) * 64 + lane] = hh == 0 ? row1 : row0;
+        }
+    }
+    lds_barrier_w();
+    const int tx = l31 & (TX - 1), ty = (l31 >> txl) & (TY - 1), tb = l31 >> (txl + tyl);
+    const int b = tb0 + tb, oy = 2 * (ty0 + ty) + hh, ox = 2 * (tx0 + tx);
+    const bool pvalid = (b < g.B) & (oy < g.OH) & (ox < g.OW);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
+    const int nw = n0 + fw * 32, pw = w ^ 2;                    // partner wave: same cout fragment, other position half
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float y0 = keep[r][0] + X[(pw * 32 + r * 2 + 0) * 64 + lane], y1 = keep[r][1] + X[(pw * 32 + r * 2 + 1) * 64 + lane];
+        const int n = nw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = pvalid & (n < g.Cout);
+        const unsigned off = (unsigned)((b * g.Cout + n) * ohw + oy * g.OW + ox) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{y0, y1}), ro, ok ? off : kOOB, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // conv4x4 stride 2 pad 1 (the discriminators' down-sampling convs), forward: polyphase + Winograd F(2x2, 2x2).
 //     out[oy][ox] = sum_{r,s} w[r][s] x[2 oy + r - 1][2 ox + s - 1]:  the odd input rows O[i] = x[2i + 1] see the taps r = 0, 2 (at O[oy - 1],
 //     O[oy]), the even rows E[i] = x[2i] the taps r = 1, 3 (at E[oy], E[oy + 1]) -- per dimension two 2-tap stride-1 filters on the two
@@ -838,6 +1016,9 @@ WinoPlan plan_wino(const Geom& g) {
     const int tw = g.OWs / 2, th = g.OHs / 2;                 // tiles per row / column of the output lattice
     if (tw < 4) return p;                                     // (4x4 maps: two tiles per row -- the direct kernel's K split serves them better)
     p.nf = g.Cout >= 96 ? 4 : 2;                             // cout fragments per workgroup; 4: 32 tiles, 2: 64 tiles
+    static const bool hoff = getenv("AGAN_WINO_H_OFF") != nullptr;
+    p.hmode = (p.s2 == 0 && !hoff) ? 1 : 0;                   // conv3x3: 32 tiles x 64 channels, two workgroups per CU (conv_wino_h_f32_kernel)
+    if (p.hmode) p.nf = 4;                                    // (tile geometry of the 32-tile blocks)
     const int lt = p.nf == 4 ? 5 : 6;
     p.txl = std::min(3, pow2floor_log(tw));
     p.tyl = std::min(lt - p.txl, pow2floor_log(th));
@@ -846,7 +1027,7 @@ WinoPlan plan_wino(const Geom& g) {
     p.blocks_y = cdiv(th, TY);
     p.blocks_b = cdiv(g.B, TB);
     p.mtiles = p.blocks_x * p.blocks_y * p.blocks_b;
-    p.ntiles = cdiv(g.Cout, p.nf * 32);
+    p.ntiles = p.hmode ? cdiv(g.Cout, 64) : cdiv(g.Cout, p.nf * 32);
     // the 32 x 32 x 2 product needs thousands of tiles to pay for a workgroup's 256 accumulators: small layers stay on the direct kernel
     // (stride 2, measured: 384 workgroups = 1.5 rounds of the chip gain nothing, 768+ do: such layers split their input channels over two
     //  workgroups and sum the halves -- their outputs are small)
@@ -899,6 +1080,12 @@ void launch_wino(const float* in, const float* wk, float* out, const Geom& g, co
         return;
     }
     hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+    if (p.hmode) {
+        static const hipError_t ah = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)ah;
+        hipLaunchKernelGGL(conv_wino_h_f32_kernel, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        return;
+    }
     if (p.nf == 4) {
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
