@@ -38,7 +38,7 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_gather_patch16 (fwd/dgrad, 16-bit MFMA)", ["conv_patch_kernel"]),
     ("conv_wgrad_rows (row-resident weight gradient, conv_wgrows.hip)", ["conv_wgrad_rows_kernel"]),
     ("conv_wgrad_patch16", ["conv_patch_wgrad_kernel"]),
-    ("conv_wino gather (fp32 Winograd: conv3x3 fwd/dgrad, conv4x4-s2 fwd + class-wise dgrad)", ["conv_wino_f32_kernel", "conv_wino_s2_f32_kernel", "conv_wino_cls_f32_kernel"]),
+    ("conv_wino gather (fp32 Winograd: conv3x3 fwd/dgrad, conv4x4-s2 fwd + class-wise dgrad)", ["conv_wino_f32_kernel", "conv_wino_h_f32_kernel", "conv_wino_s2_f32_kernel", "conv_wino_cls_f32_kernel"]),
     ("conv_wino weight gradient (fp32 Winograd F(3x3,2x2))", ["conv_wino_wgrad_f32_kernel"]),
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
     ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
@@ -73,6 +73,8 @@ def bench_name(kernel, mode):
             return f"conv_gather_f32_n{n}"
     if "conv_wgrad_f32_kernel" in kernel or "conv_wino_wgrad_f32_kernel" in kernel:
         return "conv_wgrad_f32"
+    if "conv_wino_h_f32_kernel" in kernel:        # 64-channel tiles of layers with any channel count: booked with the 128-channel family
+        return "conv_gather_f32_n128"
     for wk in ("conv_wino_f32_kernel<", "conv_wino_s2_f32_kernel<", "conv_wino_cls_f32_kernel<"):
         if wk in kernel:                      # <NFW>: cout fragments per workgroup = 128 / 64 output channels
             return "conv_gather_f32_n128" if wk + "4>" in kernel else "conv_gather_f32_n64"
