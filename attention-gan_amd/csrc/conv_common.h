@@ -321,6 +321,7 @@ struct WinoPlan {
     int blocks_x, blocks_y, blocks_b, mtiles;
     int nf, ntiles;                     // cout fragments per workgroup (4: 128 channels, 2: 64), cout tiles
     int pcp, raw_items, raw_bytes;      // raw patch: row pitch (floats), values per 8-channel chunk, LDS bytes
+    int mpc, mpr;                       // ceil(65536 / patch columns), ceil(65536 / patch rows): the item -> (row, column) divisions of the staging map
     int smem_bytes;
     int ksplit, chunks_per_split;       // stride 2: input-channel split of layers that would fill the chip 1.5 times
     size_t u_bytes, slab, ws_bytes;     // transformed weights [planes][Cin / 8][Nld][8] fp32 at the head of the workspace; partial-sum slabs behind it

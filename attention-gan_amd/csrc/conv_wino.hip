@@ -309,14 +309,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_h_f32_kernel(const float* __
     int it_off[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int e = tid + i * 256;
-        const int col = e % PC, t1 = e / PC;
-        const int row = t1 % PR, t2 = t1 / PR;
+        const int e = tid + i * 256;                               // < 2048: e / d = (e * ceil(65536 / d)) >> 16 exactly for d <= 18 (two VALU
+        const int t1 = (int)(__umul24(e, wp.mpc) >> 16), col = e - (int)__umul24(t1, PC);       // instructions instead of the ~12 of a general
+        const int t2 = (int)(__umul24(t1, wp.mpr) >> 16), row = t1 - (int)__umul24(t2, PR);     // division; 24-bit multiplies are full rate)
         const int ci = t2 & 7, tb = t2 >> 3;
         const int b = tb0 + tb, iy = 2 * ty0 - 1 + row, ix = 2 * tx0 - 1 + col;
         const bool ok = (e < wp.raw_items) & (b < g.B) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-        it_off[i] = ok ? (b * g.Cin + ci) * ihw + iy * g.IW + ix : -1;
-        it_lds[i] = (unsigned)(((tb * 8 + ci) * PR + row) * PCP + col);
+        it_off[i] = ok ? (int)__umul24(b * g.Cin + ci, ihw) + iy * g.IW + ix : -1;
+        it_lds[i] = (unsigned)((int)__umul24(__umul24(t2, PR) + row, PCP) + col);
     }
     float rawv[NI];
     auto load_raw = [&](int ch, float (&rv)[NI]) {
@@ -409,42 +409,57 @@ __global__ __launch_bounds__(256, 2) void conv_wino_h_f32_kernel(const float* __
 
     // ---- output transform: columns in registers, rows across the wave pair (fw, hh = 0 / 1).  acc[x2 * 4 + nu] = M[2 hh + x2][nu].
     //      hh = 0 holds rows 0, 1: output row 0 gets M0 + M1, row 1 gets M1;   hh = 1 holds rows 2, 3: row 0 gets M2, row 1 gets -M2 - M3.
-    //      Wave hh finishes output row hh and sends its contribution to the other row to its partner. ----
+    //      Wave hh finishes output row hh and sends its contribution to the other row to its partner.
+    //      The fp32 MFMA and the vector ALU do not overlap on gfx950 (profiles/micro/mfma_issue.hip) and this kernel runs only 256 MFMAs per
+    //      wave: every VALU instruction here is ~0.04 % of the workgroup.  So: packed adds on (r, r + 1) register pairs (consecutive
+    //      accumulator registers: no moves), one code path per hh (no selects), the register-dependent part of the store address in
+    //      the scalar offset. ----
     float* const X = reinterpret_cast<float*>(lds);            // [wave 4][32 values][64 lanes]
-    float keep[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float t[2][2];                                           // [x2][output column]
-#pragma unroll
-        for (int x2 = 0; x2 < 2; ++x2) {
-            const float m0 = acc[x2 * 4 + 0][r], m1 = acc[x2 * 4 + 1][r], m2 = acc[x2 * 4 + 2][r], m3 = acc[x2 * 4 + 3][r];
-            t[x2][0] = m0 + m1 + m2;
-            t[x2][1] = m1 - m2 - m3;
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float row0 = hh == 0 ? t[0][b] + t[1][b] : t[0][b];
-            const float row1 = hh == 0 ? t[1][b] : -t[0][b] - t[1][b];
-            keep[r][b] = hh == 0 ? row0 : row1;
-            X[(w * 32 + r * 2 + b) * 64 + lane] = hh == 0 ? row1 : row0;
-        }
-    }
-    lds_barrier_w();
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
     const int tx = l31 & (TX - 1), ty = (l31 >> txl) & (TY - 1), tb = l31 >> (txl + tyl);
     const int b = tb0 + tb, oy = 2 * (ty0 + ty) + hh, ox = 2 * (tx0 + tx);
     const bool pvalid = (b < g.B) & (oy < g.OH) & (ox < g.OW);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (size_t)g.B * g.Cout * ohw * sizeof(float));
     const int nw = n0 + fw * 32, pw = w ^ 2;                    // partner wave: same cout fragment, other position half
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const unsigned vo = pvalid ? (unsigned)((b * g.Cout + nw + 4 * lh) * ohw + oy * g.OW + ox) * 4u : kOOB;
+    auto finish = [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        f32x2_ keep[8][2];                                       // [register pair][output column]; HH = 1: the NEGATIVE of its share
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float y0 = keep[r][0] + X[(pw * 32 + r * 2 + 0) * 64 + lane], y1 = keep[r][1] + X[(pw * 32 + r * 2 + 1) * 64 + lane];
-        const int n = nw + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = pvalid & (n < g.Cout);
-        const unsigned off = (unsigned)((b * g.Cout + n) * ohw + oy * g.OW + ox) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x2_{y0, y1}), ro, ok ? off : kOOB, 0, 0);
-    }
+        for (int rp = 0; rp < 8; ++rp) {
+            f32x2_ t[2][2];                                      // [x2][output column]
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                const f32x2_ m0 = {acc[x2 * 4 + 0][2 * rp], acc[x2 * 4 + 0][2 * rp + 1]};
+                const f32x2_ m1 = {acc[x2 * 4 + 1][2 * rp], acc[x2 * 4 + 1][2 * rp + 1]};
+                const f32x2_ m2 = {acc[x2 * 4 + 2][2 * rp], acc[x2 * 4 + 2][2 * rp + 1]};
+                const f32x2_ m3 = {acc[x2 * 4 + 3][2 * rp], acc[x2 * 4 + 3][2 * rp + 1]};
+                t[x2][0] = m0 + m1 + m2;
+                t[x2][1] = m1 - m2 - m3;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                keep[rp][c] = t[0][c] + t[1][c];
+                const f32x2_ send = HH == 0 ? t[1][c] : t[0][c];
+                X[(w * 32 + (2 * rp) * 2 + c) * 64 + lane] = send[0];
+                X[(w * 32 + (2 * rp + 1) * 2 + c) * 64 + lane] = send[1];
+            }
+        }
+        lds_barrier_w();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // channels nw + (r & 3) + 8 (r >> 2) + 4 lh: a group of 8 is valid or not as a whole (Cout is a multiple of 8: plan_wino)
+            if (nw + 8 * (r >> 2) < g.Cout) {
+                const float x0 = X[(pw * 32 + r * 2 + 0) * 64 + lane], x1 = X[(pw * 32 + r * 2 + 1) * 64 + lane];
+                const float k0 = keep[r >> 1][0][r & 1], k1 = keep[r >> 1][1][r & 1];
+                const f32x2_ y = HH == 0 ? f32x2_{x0 + k0, x1 + k1} : f32x2_{x0 - k0, x1 - k1};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, y), ro, vo, (unsigned)(((r & 3) + 8 * (r >> 2)) * ohw) * 4u, 0);
+            }
+        }
+    };
+    if (hh == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -949,11 +964,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float
                     zf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + zl);
                     vf[(pos + 1) & 1] = *reinterpret_cast<const u32x4*>(cur + (pos + 1) * 64 * 8 + vl);
                 }
-                if (pos >= 1 && pos <= 8 && o + 1 < o_end) transform_piece(nxt, pos - 1);
-                if (pos >= 9 && pos <= 12) load_piece(o + 2, pos - 9);      // (past the range: zero range, nothing is fetched)
+                // no branch around the pieces (after the last octet they transform zeros into the buffer nobody reads): one basic block per
+                // position, so that the pieces can be issued BETWEEN the four MFMAs of the position (below)
+                if (pos >= 1 && pos <= 8) transform_piece(nxt, pos - 1);
+                if (pos >= 9 && pos <= 12) load_piece(o + 2, pos - 9);          // (past the range: zero range, nothing is fetched)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(zf[pos & 1][j]), __uint_as_float(vf[pos & 1][j]), acc[pos], 0, 0, 0);
+                // a wave is alone on its SIMD and issues in order: whatever FOLLOWS four back-to-back MFMAs in program order waits for all
+                // of them to issue, i.e. overlaps only the last one.  The scalar / LDS / global-load instructions of the piece are spread
+                // over the four 64-cycle shadows instead (the VALU ones cost their ~6 cycles wherever they stand: on gfx950 the fp32 MFMA
+                // and the vector ALU do not overlap -- profiles/micro/mfma_issue.hip).
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // DS read (the next position's fragments)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);          // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // DS write
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             lds_barrier_w();
@@ -1017,7 +1046,7 @@ WinoPlan plan_wino(const Geom& g) {
     if (tw < 4) return p;                                     // (4x4 maps: two tiles per row -- the direct kernel's K split serves them better)
     p.nf = g.Cout >= 96 ? 4 : 2;                             // cout fragments per workgroup; 4: 32 tiles, 2: 64 tiles
     static const bool hoff = getenv("AGAN_WINO_H_OFF") != nullptr;
-    p.hmode = (p.s2 == 0 && !hoff) ? 1 : 0;                   // conv3x3: 32 tiles x 64 channels, two workgroups per CU (conv_wino_h_f32_kernel)
+    p.hmode = (p.s2 == 0 && !hoff && (g.Cout & 7) == 0) ? 1 : 0;   // conv3x3: 32 tiles x 64 channels, two workgroups per CU (conv_wino_h_f32_kernel)
     if (p.hmode) p.nf = 4;                                    // (tile geometry of the 32-tile blocks)
     const int lt = p.nf == 4 ? 5 : 6;
     p.txl = std::min(3, pow2floor_log(tw));
@@ -1039,6 +1068,8 @@ WinoPlan plan_wino(const Geom& g) {
     const int PR = p.s2 == 2 ? 2 * TY + 1 : (p.s2 ? 4 : 2) * TY + 2, PC = p.s2 == 2 ? 2 * TX + 1 : (p.s2 ? 4 : 2) * TX + 2;
     const int cch = p.s2 == 2 ? 16 : 8;                       // channels per chunk
     p.pcp = (PC + 1) & ~1;
+    p.mpc = (65536 + PC - 1) / PC;
+    p.mpr = (65536 + PR - 1) / PR;
     p.raw_items = TB * cch * PR * PC;
     if (p.raw_items > (p.s2 == 2 ? (p.nf == 4 ? 11 : 19) : (p.s2 ? 21 : (p.nf == 4 ? 7 : 11))) * 256) return p;
     p.raw_bytes = (TB * cch * PR * p.pcp * 4 + 15) & ~15;

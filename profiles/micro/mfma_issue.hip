@@ -1,0 +1,212 @@
+// Micro-benchmark: what does one wave per SIMD lose around v_mfma_f32_32x32x2_f32 on gfx950?
+// Questions behind it (round 3, fp32 Winograd kernels at 40-55 % MFMA-busy with a clean inner loop):
+//   * is a chain of 4 dependent MFMAs (same accumulator) slower than 4 independent ones?
+//   * how much of a VALU / LDS block placed AFTER a chain of 4 is hidden, and how much when it is spread between the MFMAs?
+//   * what is the shader clock under sustained MFMA load (s_memtime cycles vs the 100 MHz wall clock)?
+//   * what do 2 waves per SIMD buy?
+//       hipcc --offload-arch=gfx950 -O3 mfma_issue.hip -o mfma_issue && ./mfma_issue
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: chains of 4 dependent MFMAs, nothing else          MODE 1: round-robin over the 16 accumulators (independent neighbours)
+// MODE 2: chain of 4, then NV VALU ops                        MODE 3: one MFMA, NV/4 VALU ops, four times (spread)
+// MODE 4: chain of 4 + 2 ds_read_b128 feeding the NEXT chain   MODE 5: as 4, plus NV VALU spread
+template <int MODE, int NV, int NACC>
+__global__ __launch_bounds__(256) void k(float* out, long long* cyc, long long* wall, int iters, float a0, float b0) {
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = (float)i * 1e-6f;
+    __syncthreads();
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float va[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va[i] = a0 + i + threadIdx.x;
+    f32x4 za = {a0, a0 + 1, a0 + 2, a0 + 3}, zb = {b0, b0 + 1, b0 + 2, b0 + 3};
+    const int lane = threadIdx.x & 63;
+    const long long w0 = wall_clock64();
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            f32x4 na = za, nb = zb;
+            if (MODE >= 4) {
+                na = *reinterpret_cast<const f32x4*>(&lds[((q * 64 + lane) * 4 + it * 16) & 8188 & ~3]);
+                nb = *reinterpret_cast<const f32x4*>(&lds[((q * 64 + lane) * 4 + 4096 + it * 16) & 8188 & ~3]);
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[(q + 4 * j) % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[j], zb[j], acc[(q + 4 * j) % NACC], 0, 0, 0);
+            } else if (MODE == 3 || MODE == 5) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[j], zb[j], acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < NV / 4; ++v) va[(v + 2 * j) & 7] = va[(v + 2 * j) & 7] * 1.0001f + va[(v + 2 * j + 1) & 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[j], zb[j], acc[q], 0, 0, 0);
+                if (MODE == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) va[v & 7] = va[v & 7] * 1.0001f + va[(v + 1) & 7];
+                }
+            }
+            za = na; zb = nb;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const long long t1 = clock64();
+    const long long w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += va[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; wall[blockIdx.x] = w1 - w0; }
+}
+
+template <int MODE, int NV, int NACC>
+void run(const char* what, int wgs_per_cu, float* out, long long* cyc, long long* wall) {
+    const int iters = 4000, nwg = 256 * wgs_per_cu;
+    long long hc[512], hw[512];
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<MODE, NV, NACC>), dim3(nwg), dim3(256), 0, 0, out, cyc, wall, iters, 1.f, 2.f);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemcpy(hc, cyc, nwg * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hw, wall, nwg * 8, hipMemcpyDeviceToHost);
+    double c = 0, w = 0;
+    for (int i = 0; i < nwg; ++i) { c += hc[i]; w += hw[i]; }
+    c /= nwg; w /= nwg;
+    const double nm = (double)iters * NACC * 4;                        // MFMAs per wave
+    const double tf = nm * 4096.0 * 4 * nwg / (ms * 1e-3) / 1e12;
+    printf("%-58s %d wg/CU: %7.1f memtime ticks / MFMA / wave, kernel %.3f ms = %.1f TF/s, wall %.3f ms, memtime %.0f MHz\n", what, wgs_per_cu,
+           c / nm, ms, tf, w / 100e6 * 1e3, c / (w / 100e6) / 1e6);
+}
+
+
+// Cost model of the memory instructions around a chain of 4 MFMAs (addresses precomputed: immediate offsets only, no VALU):
+// NR ds_read_b128 (consumed by the NEXT chain), NW ds_write_b128, NG buffer-style global 16-byte loads (L2-resident, consumed 16 chains
+// later through the LDS writes or just accumulated), BAR: one workgroup barrier per 16 chains.
+template <int NR, int NW, int NG, int BAR>
+__global__ __launch_bounds__(256) void km(float* out, long long* cyc, long long* wall, const f32x4* __restrict__ gsrc, int iters, float a0, float b0) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = (float)i * 1e-6f;
+    __syncthreads();
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    f32x4 za = {a0, a0 + 1, a0 + 2, a0 + 3}, zb = {b0, b0 + 1, b0 + 2, b0 + 3};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const f32x4* const rbase = reinterpret_cast<const f32x4*>(lds) + lane;            // 16 B per lane, 1 KB per wave-read: conflict-free
+    f32x4* const wbase = reinterpret_cast<f32x4*>(lds) + 2048 + w * 64 + lane;
+    const f32x4* gp = gsrc + (blockIdx.x & 7) * 4096 + threadIdx.x;
+    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+    const long long w0 = wall_clock64();
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            f32x4 nr[4] = {za, zb, za, zb};
+#pragma unroll
+            for (int r = 0; r < NR; ++r) nr[r] = rbase[(q * 4 + r) * 64 % 1024];
+            f32x4 gl[4];
+#pragma unroll
+            for (int r = 0; r < NG; ++r) gl[r] = gp[((q * NG + r) * 256) % 4096];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[j], zb[j], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < NW; ++r) wbase[(q * 4 + r) * 256 % 2048] = gacc;
+#pragma unroll
+            for (int r = 0; r < NG; ++r) gacc += gl[r];
+            if (NR > 0) { za = nr[0]; zb = nr[NR > 1 ? 1 : 0]; }
+            if (NR > 2) { za += nr[2]; }
+            if (NR > 3) { zb += nr[3]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (BAR) __syncthreads();
+    }
+    const long long t1 = clock64();
+    const long long w1 = wall_clock64();
+    float s = gacc[0] + gacc[1] + gacc[2] + gacc[3];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; wall[blockIdx.x] = w1 - w0; }
+}
+
+template <int NR, int NW, int NG, int BAR>
+void runm(const char* what, float* out, long long* cyc, long long* wall, const f32x4* gsrc) {
+    const int iters = 4000, nwg = 256;
+    long long hc[512];
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((km<NR, NW, NG, BAR>), dim3(nwg), dim3(256), 0, 0, out, cyc, wall, gsrc, iters, 1.f, 2.f);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemcpy(hc, cyc, nwg * 8, hipMemcpyDeviceToHost);
+    double c = 0;
+    for (int i = 0; i < nwg; ++i) c += hc[i];
+    c /= nwg;
+    const double nm = (double)iters * 16 * 4;
+    printf("%-58s : %7.1f cycles / chain of 4 MFMAs (256 = MFMA-bound), %.1f TF/s\n", what, 4 * c / nm, nm * 4096.0 * 4 * nwg / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    float* out; long long *cyc, *wall;
+    hipMalloc(&out, 512 * 256 * 4); hipMalloc(&cyc, 512 * 8); hipMalloc(&wall, 512 * 8);
+    run<0, 0, 16>("chains of 4 dependent MFMAs", 1, out, cyc, wall);
+    run<1, 0, 16>("independent neighbours", 1, out, cyc, wall);
+    run<2, 8, 16>("chain of 4 then 8 VALU", 1, out, cyc, wall);
+    run<2, 16, 16>("chain of 4 then 16 VALU", 1, out, cyc, wall);
+    run<2, 32, 16>("chain of 4 then 32 VALU", 1, out, cyc, wall);
+    run<3, 16, 16>("16 VALU spread between the 4 MFMAs", 1, out, cyc, wall);
+    run<3, 32, 16>("32 VALU spread between the 4 MFMAs", 1, out, cyc, wall);
+    run<3, 48, 16>("48 VALU spread between the 4 MFMAs", 1, out, cyc, wall);
+    run<4, 0, 16>("chain of 4 + 2 ds_read_b128 for the next chain", 1, out, cyc, wall);
+    run<5, 32, 16>("the same + 32 VALU spread", 1, out, cyc, wall);
+    run<0, 0, 8>("chains of 4, 8 accumulators", 2, out, cyc, wall);
+    run<2, 32, 8>("chain of 4 then 32 VALU, 8 accumulators", 2, out, cyc, wall);
+    run<5, 32, 8>("chain + ds_read + 32 VALU spread, 8 accumulators", 2, out, cyc, wall);
+    f32x4* gsrc;
+    hipMalloc(&gsrc, 8 * 4096 * 16);
+    hipMemset(gsrc, 0, 8 * 4096 * 16);
+    runm<0, 0, 0, 0>("chain only", out, cyc, wall, gsrc);
+    runm<1, 0, 0, 0>("+ 1 ds_read_b128", out, cyc, wall, gsrc);
+    runm<2, 0, 0, 0>("+ 2 ds_read_b128", out, cyc, wall, gsrc);
+    runm<3, 0, 0, 0>("+ 3 ds_read_b128", out, cyc, wall, gsrc);
+    runm<4, 0, 0, 0>("+ 4 ds_read_b128", out, cyc, wall, gsrc);
+    runm<0, 1, 0, 0>("+ 1 ds_write_b128", out, cyc, wall, gsrc);
+    runm<0, 2, 0, 0>("+ 2 ds_write_b128", out, cyc, wall, gsrc);
+    runm<0, 0, 1, 0>("+ 1 global 16-byte load", out, cyc, wall, gsrc);
+    runm<0, 0, 2, 0>("+ 2 global 16-byte loads", out, cyc, wall, gsrc);
+    runm<0, 0, 0, 1>("+ a barrier per 16 chains", out, cyc, wall, gsrc);
+    runm<2, 0, 0, 1>("+ 2 ds_read_b128 + a barrier per 16 chains", out, cyc, wall, gsrc);
+    runm<3, 1, 1, 1>("3 reads, 1 write, 1 global load, barrier (direct gather)", out, cyc, wall, gsrc);
+    return 0;
+}
