@@ -1178,10 +1178,8 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
             launch_wino_wgrad(x, dy, wsf, g, wp, st);
             timer_end(st);
             if (int e = check_launch("conv_wgrad/winograd")) return e;
-            const size_t n = (size_t)g.Cout * g.Cin * 9;
-            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, wp.psplit, n,
-                               wp.slab, (const float*)nullptr, 1, 1, dw, accumulate ? 1 : 0);
-            return check_launch("conv_wgrad/winograd/sum_slabs");
+            launch_wino_wgrad_sum(wsf, g, wp, dw, accumulate ? 1 : 0, st);
+            return check_launch("conv_wgrad/winograd/sum");
         }
     }
     if (!(prec == AGAN_PREC_F32 && small_n_wgrad_supported(g))) {

@@ -332,6 +332,7 @@ struct WinoWgradPlan {
 };
 WinoWgradPlan plan_wino_wgrad(const Geom& g);
 void launch_wino_wgrad(const float* x, const float* dy, float* part, const Geom& g, const WinoWgradPlan& p, hipStream_t st);
+void launch_wino_wgrad_sum(const float* part, const Geom& g, const WinoWgradPlan& p, float* dw, int accumulate, hipStream_t st);   // slabs [tap][cout][cin] -> OIHW
 WinoPlan plan_wino(const Geom& g);
 void launch_wino(const float* in, const float* wk, float* out, const Geom& g, const WinoPlan& p, void* ws, hipStream_t st);
 int prec_planes(int prec);

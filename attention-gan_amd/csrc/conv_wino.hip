@@ -989,12 +989,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float
         }
     }
 
-    // ---- dw = A^T M A in registers; D[cout][cin]: lane l31 = input channel, register -> output channel; 9 taps contiguous in OIHW ----
+    // ---- dw = A^T M A in registers; D[cout][cin]: lane l31 = input channel, register -> output channel.  The slab is [tap][cout][cin]:
+    //      a store instruction writes 128 contiguous bytes per half wave (OIHW would scatter its lanes 36 bytes apart: the 38 MB of slabs
+    //      of a 128-way pixel split took 30 us that way); wino_wgrad_sum_kernel transposes while it sums.  Addresses: lane part in the
+    //      vector offset once, (register, tap) part in the scalar offset. ----
     float* const o = part + (size_t)split * wp.slab;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)g.Cout * g.Cin * 9 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o, (size_t)9 * g.Cout * g.Cin * sizeof(float));
     const int ci = i0 + fi * 32 + l31;
+    const int cob = j0 + fj * 32;                                // + (r & 3) + 8 (r >> 2) + 4 lh
+    const unsigned vo = ci < g.Cin ? (unsigned)(4 * lh * g.Cin + ci) * 4u : kOOB;
+    const unsigned tapb = (unsigned)(g.Cout * g.Cin) * 4u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+        if (cob + 8 * (r >> 2) >= g.Cout) continue;             // (a group of 8 channels is valid as a whole: Cout is a multiple of 8)
         float c[3][4];                                           // rows of A^T M
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
@@ -1003,15 +1010,51 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const float
             c[1][nu] = m1 - m2;
             c[2][nu] = m1 + m2 + m3;
         }
-        const int co = j0 + fj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = (co < g.Cout) & (ci < g.Cin);
-        const unsigned base = (unsigned)((co * g.Cin + ci) * 9) * 4u;
+        const unsigned so = (unsigned)((cob + (r & 3) + 8 * (r >> 2)) * g.Cin) * 4u;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
-            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 0) * 4u : kOOB, c[rr][0] + c[rr][1] + c[rr][2]);
-            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 1) * 4u : kOOB, c[rr][1] - c[rr][2]);
-            buf_store(ro, ok ? base + (unsigned)(rr * 3 + 2) * 4u : kOOB, c[rr][1] + c[rr][2] + c[rr][3]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[rr][0] + c[rr][1] + c[rr][2]), ro, vo, so + (unsigned)(rr * 3 + 0) * tapb, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[rr][1] - c[rr][2]), ro, vo, so + (unsigned)(rr * 3 + 1) * tapb, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[rr][1] + c[rr][2] + c[rr][3]), ro, vo, so + (unsigned)(rr * 3 + 2) * tapb, 0);
         }
+    }
+}
+
+// dw[cout][cin][tap] (+)= sum over the pixel-split slabs [tap][cout][cin].  As conv.hip's sum_slabs_kernel: a workgroup covers 32 float4
+// elements (4 consecutive input channels of one (tap, cout)) x 8 slab groups, a thread adds every 8th slab with 4 loads in flight, the 8
+// partial sums meet in LDS; the first group transposes on the way out.  Fixed summation order: reproducible.
+__global__ __launch_bounds__(256) void wino_wgrad_sum_kernel(const float* __restrict__ part, int nslabs, size_t slab, int cout, int cin,
+                                                             float* __restrict__ dw, int accumulate) {
+    __shared__ f32x4 red[8][32];
+    const int q4 = cin >> 2, n4 = 9 * cout * q4;
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (int base = blockIdx.x * 32; base < n4; base += gridDim.x * 32) {
+        const int e = base + el;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (e < n4) {
+            const float* src = part + (size_t)e * 4;
+            int sp = grp;
+            for (; sp + 24 < nslabs; sp += 32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 8) * slab);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 16) * slab);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 24) * slab);
+                a += (v0 + v1) + (v2 + v3);
+            }
+            for (; sp < nslabs; sp += 8) a += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+        }
+        red[grp][el] = a;
+        __syncthreads();
+        if (grp == 0 && e < n4) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) a += red[k][el];
+            const int c4 = e % q4, t1 = e / q4;
+            const int co = t1 % cout, tap = t1 / cout;
+            float* dst = dw + ((size_t)co * cin + 4 * c4) * 9 + tap;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k * 9] = accumulate ? dst[k * 9] + a[k] : a[k];
+        }
+        __syncthreads();
     }
 }
 
@@ -1136,7 +1179,7 @@ WinoWgradPlan plan_wino_wgrad(const Geom& g) {
     static const bool off = getenv("AGAN_WINO_OFF") != nullptr || getenv("AGAN_WINO_WGRAD_OFF") != nullptr;
     if (off) return p;
     if (!(g.SY == 1 && g.R == 3 && g.S == 3 && g.DY == 1 && g.OS == 1 && g.OY0 == -1)) return p;
-    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 15) || g.Cin < 32 || g.Cout < 32) return p;
+    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 15) || g.Cin < 32 || g.Cout < 32 || (g.Cin & 3) || (g.Cout & 7)) return p;
     p.noct = g.B * (g.OH / 2) * (g.OW / 16);
     p.jtiles = cdiv(g.Cout, 64);
     p.itiles = cdiv(g.Cin, 64);
@@ -1156,6 +1199,11 @@ void launch_wino_wgrad(const float* x, const float* dy, float* part, const Geom&
     static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)a;
     hipLaunchKernelGGL(conv_wino_wgrad_f32_kernel, dim3(p.jtiles * p.itiles * p.psplit), dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p);
+}
+
+void launch_wino_wgrad_sum(const float* part, const Geom& g, const WinoWgradPlan& p, float* dw, int accumulate, hipStream_t st) {
+    const int n4 = 9 * g.Cout * (g.Cin >> 2);
+    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(std::min(cdiv(n4, 32), 8192)), dim3(256), 0, st, part, p.psplit, p.slab, g.Cout, g.Cin, dw, accumulate);
 }
 
 }  // namespace conv

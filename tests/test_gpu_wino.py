@@ -24,8 +24,9 @@ TOL = 3e-5          # max |error| / max |reference| per tensor
 CASES = [
     # kind, B, Cin, H, W, Cout, what
     ("same", 8, 16, 64, 64, 128, "3x3: 128-channel tiles, 4 x 8 tile blocks"),
-    ("same", 4, 24, 128, 128, 64, "3x3: 64-channel tiles of 64 tiles (8 x 8 blocks), weight gradient with an input-channel tail"),
+    ("same", 4, 24, 128, 128, 64, "3x3: 64-channel tiles of 64 tiles (8 x 8 blocks); 24 input channels: weight gradient on the row-resident kernel"),
     ("same", 12, 8, 40, 96, 160, "3x3: ragged block rows (20 tile rows / 4), two cout tiles, the second half empty"),
+    ("same", 4, 40, 128, 128, 72, "3x3: Winograd weight gradient (2048 tile octets) with an input-channel tail (40 of 64) and an output-channel tail (8 of 64 in the second tile): [tap][cout][cin] slabs, transposing sum"),
     ("same", 64, 32, 16, 16, 128, "3x3: 16 x 16 maps (two 4 x 8 blocks per image); too few tile octets for the Winograd weight gradient -> row-resident kernel"),
     ("down", 16, 16, 128, 128, 128, "4x4 s2 forward: polyphase, 512 workgroups; data gradient: 64 output channels -> direct kernel"),
     ("down", 8, 128, 128, 128, 128, "4x4 s2 forward: 256 workgroups -> input-channel split + slab sum; data gradient: class-wise Winograd"),
