@@ -16,5 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${TAG}_
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 $LOWC --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_mfma -o p -- $B --single-stream > /dev/null 2>&1 &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_fetch -o p -- $B --single-stream > /dev/null 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_write -o p -- $B --single-stream > /dev/null 2>&1 &&
+# (instruction mix: on gfx950 the fp32 MFMA shares the vector lanes with the VALU -- DESIGN.md §4 "What an fp32 MFMA kernel pays for" -- so the
+#  non-MFMA VALU instructions per MFMA instruction of a family say how far it can get; optional: a failure here does not stop the summary)
+{ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $R/gpurun_out/ev_${TAG}_insts -o p -- $B --single-stream > /dev/null 2>&1 || rm -rf $R/gpurun_out/ev_${TAG}_insts; } &&
 cd $R && python3 profiles/make_counters.py gpurun_out/ev_${TAG} gpurun_out ${TAG} > gpurun_out/ev_${TAG}_summary.txt 2>&1
 tail -3 gpurun_out/ev_${TAG}_summary.txt

@@ -122,6 +122,15 @@ def main():
         f["busy"] += d["c"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         f["gui"] += d["c"].get("GRBM_GUI_ACTIVE", 0.0)
         f["mops"] += sum(d["c"].get("SQ_INSTS_VALU_MFMA_MOPS_" + t, 0.0) for t in ("F32", "BF16", "F16"))
+    # optional instruction-mix pass (collect_evidence.sh): VALU / MFMA / SALU / LDS instructions issued, per family
+    insts = {}
+    if glob.glob(os.path.join(prefix + "_insts", "**", "*counter_collection.csv"), recursive=True):
+        for d in read_pass(prefix + "_insts").values():
+            i = insts.setdefault(family_of(d["kernel"]), {"valu": 0.0, "mfma": 0.0, "salu": 0.0, "lds": 0.0})
+            i["valu"] += d["c"].get("SQ_INSTS_VALU", 0.0)
+            i["mfma"] += d["c"].get("SQ_INSTS_MFMA", 0.0)
+            i["salu"] += d["c"].get("SQ_INSTS_SALU", 0.0)
+            i["lds"] += d["c"].get("SQ_INSTS_LDS", 0.0)
     conv = {}
     for src, key, cnt in ((fetch, "fetch", "nf"), (write, "write", "nw")):
         name = "FETCH_SIZE" if key == "fetch" else "WRITE_SIZE"
@@ -146,10 +155,16 @@ def main():
                      # effective shader clock while the family's kernels ran: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md,
                      # DVFS give-back); reads high for dispatches much shorter than 0.3 ms
                      round(f["gui"] / 8.0 / f["ns"], 2) if f["ns"] and f["gui"] else ""])
+        if insts:
+            i = insts.get(name)
+            # SQ_INSTS_VALU counts the MFMAs too: the other vector instructions, the scalar and the LDS instructions, per MFMA instruction
+            rows[-1] += ([round((i["valu"] - i["mfma"]) / i["mfma"], 2), round(i["salu"] / i["mfma"], 2), round(i["lds"] / i["mfma"], 2)]
+                         if i and i["mfma"] > 0 else ["", "", ""])
     with open(os.path.join(out_dir, f"{tag}_kernel_family_counters.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel_family", "launches", "avg_us", "pct_of_kernel_time", "mfma_util_pct", "mfma_mops_per_launch",
-                    "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s", "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)"])
+                    "hbm_MB_per_launch(2*FETCH+WRITE)", "hbm_GB_per_s", "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)"] +
+                   (["other_valu_insts_per_mfma", "salu_insts_per_mfma", "lds_insts_per_mfma"] if insts else []))
         w.writerows(rows)
     # per LAYER rows for the row-block gathers: one row per (kernel instance, grid), i.e. per layer shape -- the family average above mixes
     # 0.4 ms layers with 15 us ones
