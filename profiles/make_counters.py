@@ -43,7 +43,7 @@ FAMILIES = [  # (family, substrings any of which selects the kernel)
     ("conv_gather_f32 (fwd/dgrad)", ["conv_gather_f32_kernel"]),
     ("conv_wgrad_f32", ["conv_wgrad_f32_kernel"]),
     ("conv_small_n (RGB heads, image gradient)", ["small_n_kernel", "small_strip_kernel"]),
-    ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel", "wino_wgrad_sum_kernel"]),
+    ("sum_slabs (split-K / split-pixel combine)", ["sum_slabs_kernel", "wino_wgrad_sum_kernel", "sum_unpack_wgrad_kernel"]),
     ("weight packs", ["pack_", "weight_transform_kernel"]),
     ("absmax (f16x3: max|x| of small tensors)", ["absmax_kernel"]),
     ("bn_stats_partial", ["bn_stats_partial"]),

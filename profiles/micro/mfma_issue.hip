@@ -177,6 +177,78 @@ void runm(const char* what, float* out, long long* cyc, long long* wall, const f
     printf("%-58s : %7.1f cycles / chain of 4 MFMAs (256 = MFMA-bound), %.1f TF/s\n", what, 4 * c / nm, nm * 4096.0 * 4 * nwg / (ms * 1e-3) / 1e12);
 }
 
+// The same question for the 16-bit matrix core: chains of 4 v_mfma_f32_32x32x16_bf16 (8 passes = 32 cycles each at full rate), NV fp32 VALU
+// FMAs after each chain (MODE 2) or spread between its MFMAs (MODE 3); one or two workgroups per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int MODE, int NV, int NACC>
+__global__ __launch_bounds__(256) void kb(float* out, long long* cyc, int iters, float a0) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float va[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va[i] = a0 + i + threadIdx.x;
+    bf16x8 za, zb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { za[i] = (__bf16)(a0 + i); zb[i] = (__bf16)(a0 - i); }
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            if (MODE == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, zb, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < NV / 4; ++v) va[(v + 2 * j) & 7] = va[(v + 2 * j) & 7] * 1.0001f + va[(v + 2 * j + 1) & 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, zb, acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) va[v & 7] = va[v & 7] * 1.0001f + va[(v + 1) & 7];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += va[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE, int NV, int NACC>
+void runb(const char* what, int wgs_per_cu, float* out, long long* cyc) {
+    const int iters = 4000, nwg = 256 * wgs_per_cu;
+    long long hc[512];
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kb<MODE, NV, NACC>), dim3(nwg), dim3(256), 0, 0, out, cyc, iters, 1.f);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemcpy(hc, cyc, nwg * 8, hipMemcpyDeviceToHost);
+    double c = 0;
+    for (int i = 0; i < nwg; ++i) c += hc[i];
+    c /= nwg;
+    const double nm = (double)iters * NACC * 4;
+    printf("bf16 %-53s %d wg/CU: %7.1f cycles / chain of 4 per wave, %.0f TF/s\n", what, wgs_per_cu, 4 * c / nm, nm * 32768.0 * 4 * nwg / (ms * 1e-3) / 1e12);
+}
+
 int main() {
     float* out; long long *cyc, *wall;
     hipMalloc(&out, 512 * 256 * 4); hipMalloc(&cyc, 512 * 8); hipMalloc(&wall, 512 * 8);
@@ -208,5 +280,14 @@ int main() {
     runm<0, 0, 0, 1>("+ a barrier per 16 chains", out, cyc, wall, gsrc);
     runm<2, 0, 0, 1>("+ 2 ds_read_b128 + a barrier per 16 chains", out, cyc, wall, gsrc);
     runm<3, 1, 1, 1>("3 reads, 1 write, 1 global load, barrier (direct gather)", out, cyc, wall, gsrc);
+    runb<2, 0, 16>("chains of 4 x 32x32x16 bf16", 1, out, cyc);
+    runb<2, 8, 16>("chain of 4 then 8 VALU", 1, out, cyc);
+    runb<2, 16, 16>("chain of 4 then 16 VALU", 1, out, cyc);
+    runb<3, 16, 16>("16 VALU spread between the 4 MFMAs", 1, out, cyc);
+    runb<3, 32, 16>("32 VALU spread between the 4 MFMAs", 1, out, cyc);
+    runb<2, 0, 8>("chains of 4, 8 accumulators", 2, out, cyc);
+    runb<2, 16, 8>("chain of 4 then 16 VALU, 8 accumulators", 2, out, cyc);
+    runb<2, 32, 8>("chain of 4 then 32 VALU, 8 accumulators", 2, out, cyc);
+    runb<3, 32, 8>("32 VALU spread, 8 accumulators", 2, out, cyc);
     return 0;
 }
