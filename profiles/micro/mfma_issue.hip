@@ -1,4 +1,4 @@
-// Micro-benchmark: what does one wave per SIMD lose around v_mfma_f32_32x32x2_f32 on gfx950?
+// Micro-benchmark: what does a wave lose around v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 on gfx950, and what does another wave get for free?
 // Questions behind it (round 3, fp32 Winograd kernels at 40-55 % MFMA-busy with a clean inner loop):
 //   * is a chain of 4 dependent MFMAs (same accumulator) slower than 4 independent ones?
 //   * how much of a VALU / LDS block placed AFTER a chain of 4 is hidden, and how much when it is spread between the MFMAs?
@@ -249,6 +249,70 @@ void runb(const char* what, int wgs_per_cu, float* out, long long* cyc) {
     printf("bf16 %-53s %d wg/CU: %7.1f cycles / chain of 4 per wave, %.0f TF/s\n", what, wgs_per_cu, 4 * c / nm, nm * 32768.0 * 4 * nwg / (ms * 1e-3) / 1e12);
 }
 
+// Do the MFMAs of ONE wave overlap the VALU instructions of ANOTHER wave on the same SIMD?  (The symmetric runs above cannot tell: two
+// waves running the same program stay in phase -- both want the matrix pipe, then both want the VALU.)  One workgroup of 8 waves per CU:
+// waves 0-3 (one per SIMD) run only MFMA chains, waves 4-7 only fp32 FMAs; ROLES bit 0 / 1 enables them.  Each role reports its own cycles.
+template <int F32, int ROLES>
+__global__ __launch_bounds__(512) void kx(float* out, long long* cyc, int iters, float a0) {
+    const int w = threadIdx.x >> 6;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float va[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va[i] = a0 + i + threadIdx.x;
+    bf16x8 za, zb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { za[i] = (__bf16)(a0 + i); zb[i] = (__bf16)(a0 - i); }
+    const long long t0 = clock64();
+    if (w < 4) {
+        if (ROLES & 1)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (F32) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], va[j + 4], acc[q], 0, 0, 0);
+                        else acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, zb, acc[q], 0, 0, 0);
+                    }
+            }
+    } else if (ROLES & 2) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int v = 0; v < 64; ++v) va[v & 7] = va[v & 7] * 1.0001f + va[(v + 1) & 7];
+        }
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += va[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+}
+
+template <int F32, int ROLES>
+void runx(const char* what, float* out, long long* cyc) {
+    const int iters = 4000, nwg = 256;
+    static long long hc[256 * 8];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((kx<F32, ROLES>), dim3(nwg), dim3(512), 0, 0, out, cyc, iters, 1.f);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(hc, cyc, nwg * 8 * 8, hipMemcpyDeviceToHost);
+    double cm = 0, cv = 0;
+    for (int i = 0; i < nwg; ++i)
+        for (int w = 0; w < 8; ++w) (w < 4 ? cm : cv) += hc[i * 8 + w];
+    cm /= nwg * 4; cv /= nwg * 4;
+    printf("%s %-44s: MFMA waves %6.1f cycles per MFMA, VALU waves %5.2f cycles per FMA\n", F32 ? "f32 " : "bf16", what,
+           (ROLES & 1) ? cm / (iters * 16.0) : 0.0, (ROLES & 2) ? cv / (iters * 64.0) : 0.0);
+}
+
 int main() {
     float* out; long long *cyc, *wall;
     hipMalloc(&out, 512 * 256 * 4); hipMalloc(&cyc, 512 * 8); hipMalloc(&wall, 512 * 8);
@@ -289,5 +353,12 @@ int main() {
     runb<2, 16, 8>("chain of 4 then 16 VALU, 8 accumulators", 2, out, cyc);
     runb<2, 32, 8>("chain of 4 then 32 VALU, 8 accumulators", 2, out, cyc);
     runb<3, 32, 8>("32 VALU spread, 8 accumulators", 2, out, cyc);
+    hipFree(cyc); hipMalloc(&cyc, 256 * 8 * 8);
+    runx<1, 1>("MFMA waves alone", out, cyc);
+    runx<1, 2>("VALU waves alone", out, cyc);
+    runx<1, 3>("both: one MFMA wave + one VALU wave per SIMD", out, cyc);
+    runx<0, 1>("MFMA waves alone", out, cyc);
+    runx<0, 2>("VALU waves alone", out, cyc);
+    runx<0, 3>("both: one MFMA wave + one VALU wave per SIMD", out, cyc);
     return 0;
 }
