@@ -296,6 +296,12 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv_wgrad_rows_kernel(cons
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             if (kk + 1 < NK) read_frags(buf, kk + 1, bf[(kk + 1) & 1], af[(kk + 1) & 1]);
+#ifndef AGAN_WG_NOPIN
+            // keep the next k-step's LDS reads HERE, in front of this k-step's MFMAs: left alone, the scheduler sank them behind the MFMAs
+            // and every k-step waited out the LDS latency of its own fragments.  (Consumer waves alone, producers idle: 56 -> 52 us on the
+            // bf16 stride-2 layers; the full kernel, 74 us, did not move -- profiles/r03_rows_ablation.txt has where its time goes.)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // the three shifted dy fragments av[0] = dy[j-1 ..], av[1] = dy[j ..], av[2] = dy[j+1 ..]
             u32x4 av[3][NPL];
 #pragma unroll
