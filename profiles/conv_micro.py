@@ -3,7 +3,9 @@
     python profiles/conv_micro.py --precision bf16 --storage bf16 [--layers d256] [--iters 20]
 
 Prints per layer and phase: microseconds (torch events on the launch stream, best of 3 bursts), algorithmic TFLOP/s, algorithmic GB/s.
-Under `rocprofv3 --pmc ...` use --iters 3."""
+The burst goes through autograd + ctypes: below ~85 us per call it measures the HOST (an empty kernel reads 83 us) -- for the 16-bit
+layers and for ablations take the kernel durations of `rocprofv3 --kernel-trace -- python3 profiles/conv_micro.py ... --iters 10` instead
+(profiles/r03_rows_ablation.txt was made that way).  Under `rocprofv3 --pmc ...` use --iters 3."""
 import argparse
 import importlib
 import os
