@@ -74,3 +74,37 @@ def test_padding_rows_and_columns_are_zero_not_neighbours():
     y = HF.conv2d(x.to(DEV), w.to(DEV), None, "same").cpu()
     yr = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1).float()
     assert float((y - yr).abs().max()) <= 1e-5 * float(yr.abs().max())
+
+
+def test_winograd_weight_gradient_accumulates_in_place():
+    """agan_conv_wgrad with accumulate = 1 on a geometry the Winograd weight gradient takes (2048 tile octets): the transposing slab sum adds
+    into dw instead of overwriting it (the optimiser's flat gradient buffers are written that way); accumulate = 0 ignores what was there."""
+    import ctypes
+    HF.set_precision(L.PREC_F32)
+    lib = L.load()
+    B, Cin, H, W, Cout = 4, 40, 128, 128, 72
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = probe((B, Cout, H, W), 0.3)
+    xr = x.double()
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xr, wr, None, 1, 1).backward(dy.double())
+    ref = wr.grad.float()
+    gf, pf = HF.conv_geoms("same", B, Cin, H, W, Cout, 3)[:2]
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    nbytes = lib.agan_conv_wgrad_ws_bytes(ctypes.byref(gf))
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+    kt = HF.ktable(gf, xd.device)
+    dw = torch.full((Cout, Cin, 3, 3), 7.0, device=DEV)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(acc):
+        L.call("agan_conv_wgrad", ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(dyd.data_ptr()), ctypes.c_void_p(dw.data_ptr()), ctypes.byref(gf),
+               ctypes.c_void_p(kt.data_ptr()), pf, 3, 3, L.PREC_F32, acc, ctypes.c_void_p(ws.data_ptr()), int(nbytes), stream, None, None)
+
+    call(0)
+    first = dw.cpu().clone()
+    assert float((first - ref).abs().max() / ref.abs().max()) <= TOL
+    call(1)
+    second = dw.cpu()
+    assert float((second - 2.0 * first).abs().max() / ref.abs().max()) <= 1e-6
