@@ -13,8 +13,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // MODE 0: chains of 4 dependent MFMAs, nothing else          MODE 1: round-robin over the 16 accumulators (independent neighbours)
 // MODE 2: chain of 4, then NV VALU ops                        MODE 3: one MFMA, NV/4 VALU ops, four times (spread)
 // MODE 4: chain of 4 + 2 ds_read_b128 feeding the NEXT chain   MODE 5: as 4, plus NV VALU spread
-template <int MODE, int NV, int NACC>
-__global__ __launch_bounds__(256) void k(float* out, long long* cyc, long long* wall, int iters, float a0, float b0) {
+template <int MODE, int NV, int NACC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k(float* out, long long* cyc, long long* wall, int iters, float a0, float b0) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = (float)i * 1e-6f;
     __syncthreads();
@@ -75,16 +75,19 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, long long* 
     if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; wall[blockIdx.x] = w1 - w0; }
 }
 
+// wgs_per_cu = 2: ONE workgroup of 512 threads per CU (two waves per SIMD, certainly co-resident; two 256-thread workgroups per CU
+// turned out to run one after the other on this dispatcher: their per-workgroup wall time was half the kernel time)
 template <int MODE, int NV, int NACC>
 void run(const char* what, int wgs_per_cu, float* out, long long* cyc, long long* wall) {
-    const int iters = 4000, nwg = 256 * wgs_per_cu;
+    const int iters = 4000, nwg = 256;
     long long hc[512], hw[512];
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<MODE, NV, NACC>), dim3(nwg), dim3(256), 0, 0, out, cyc, wall, iters, 1.f, 2.f);
+        if (wgs_per_cu == 2) hipLaunchKernelGGL((k<MODE, NV, NACC, 512>), dim3(nwg), dim3(512), 0, 0, out, cyc, wall, iters, 1.f, 2.f);
+        else hipLaunchKernelGGL((k<MODE, NV, NACC, 256>), dim3(nwg), dim3(256), 0, 0, out, cyc, wall, iters, 1.f, 2.f);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1);
@@ -95,8 +98,8 @@ void run(const char* what, int wgs_per_cu, float* out, long long* cyc, long long
     for (int i = 0; i < nwg; ++i) { c += hc[i]; w += hw[i]; }
     c /= nwg; w /= nwg;
     const double nm = (double)iters * NACC * 4;                        // MFMAs per wave
-    const double tf = nm * 4096.0 * 4 * nwg / (ms * 1e-3) / 1e12;
-    printf("%-58s %d wg/CU: %7.1f memtime ticks / MFMA / wave, kernel %.3f ms = %.1f TF/s, wall %.3f ms, memtime %.0f MHz\n", what, wgs_per_cu,
+    const double tf = nm * 4096.0 * 4 * wgs_per_cu * nwg / (ms * 1e-3) / 1e12;
+    printf("%-58s %d waves/SIMD: %7.1f memtime ticks / MFMA / wave, kernel %.3f ms = %.1f TF/s, wall %.3f ms, memtime %.0f MHz\n", what, wgs_per_cu,
            c / nm, ms, tf, w / 100e6 * 1e3, c / (w / 100e6) / 1e6);
 }
 
@@ -180,8 +183,8 @@ void runm(const char* what, float* out, long long* cyc, long long* wall, const f
 // The same question for the 16-bit matrix core: chains of 4 v_mfma_f32_32x32x16_bf16 (8 passes = 32 cycles each at full rate), NV fp32 VALU
 // FMAs after each chain (MODE 2) or spread between its MFMAs (MODE 3); one or two workgroups per CU.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int MODE, int NV, int NACC>
-__global__ __launch_bounds__(256) void kb(float* out, long long* cyc, int iters, float a0) {
+template <int MODE, int NV, int NACC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void kb(float* out, long long* cyc, int iters, float a0) {
     f32x16 acc[NACC];
 #pragma unroll
     for (int q = 0; q < NACC; ++q)
@@ -229,14 +232,15 @@ __global__ __launch_bounds__(256) void kb(float* out, long long* cyc, int iters,
 
 template <int MODE, int NV, int NACC>
 void runb(const char* what, int wgs_per_cu, float* out, long long* cyc) {
-    const int iters = 4000, nwg = 256 * wgs_per_cu;
+    const int iters = 4000, nwg = 256;
     long long hc[512];
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((kb<MODE, NV, NACC>), dim3(nwg), dim3(256), 0, 0, out, cyc, iters, 1.f);
+        if (wgs_per_cu == 2) hipLaunchKernelGGL((kb<MODE, NV, NACC, 512>), dim3(nwg), dim3(512), 0, 0, out, cyc, iters, 1.f);
+        else hipLaunchKernelGGL((kb<MODE, NV, NACC, 256>), dim3(nwg), dim3(256), 0, 0, out, cyc, iters, 1.f);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1);
@@ -246,14 +250,14 @@ void runb(const char* what, int wgs_per_cu, float* out, long long* cyc) {
     for (int i = 0; i < nwg; ++i) c += hc[i];
     c /= nwg;
     const double nm = (double)iters * NACC * 4;
-    printf("bf16 %-53s %d wg/CU: %7.1f cycles / chain of 4 per wave, %.0f TF/s\n", what, wgs_per_cu, 4 * c / nm, nm * 32768.0 * 4 * nwg / (ms * 1e-3) / 1e12);
+    printf("bf16 %-53s %d waves/SIMD: %7.1f cycles / chain of 4 per wave, %.0f TF/s\n", what, wgs_per_cu, 4 * c / nm, nm * 32768.0 * 4 * wgs_per_cu * nwg / (ms * 1e-3) / 1e12);
 }
 
 // Do the MFMAs of ONE wave overlap the VALU instructions of ANOTHER wave on the same SIMD?  (The symmetric runs above cannot tell: two
 // waves running the same program stay in phase -- both want the matrix pipe, then both want the VALU.)  One workgroup of 8 waves per CU:
 // waves 0-3 (one per SIMD) run only MFMA chains, waves 4-7 only fp32 FMAs; ROLES bit 0 / 1 enables them.  Each role reports its own cycles.
-template <int F32, int ROLES>
-__global__ __launch_bounds__(512) void kx(float* out, long long* cyc, int iters, float a0) {
+template <int F32, int ROLES, int NMW = 1, int NVW = 1>
+__global__ __launch_bounds__(256 * (NMW + NVW)) void kx(float* out, long long* cyc, int iters, float a0) {
     const int w = threadIdx.x >> 6;
     f32x16 acc[4];
 #pragma unroll
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512) void kx(float* out, long long* cyc, int iters,
 #pragma unroll
     for (int i = 0; i < 8; ++i) { za[i] = (__bf16)(a0 + i); zb[i] = (__bf16)(a0 - i); }
     const long long t0 = clock64();
-    if (w < 4) {
+    if (w < 4 * NMW) {
         if (ROLES & 1)
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -293,24 +297,31 @@ __global__ __launch_bounds__(512) void kx(float* out, long long* cyc, int iters,
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += va[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + w] = t1 - t0;
 }
 
-template <int F32, int ROLES>
+template <int F32, int ROLES, int NMW = 1, int NVW = 1>
 void runx(const char* what, float* out, long long* cyc) {
     const int iters = 4000, nwg = 256;
-    static long long hc[256 * 8];
+    static long long hc[256 * 16];
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((kx<F32, ROLES>), dim3(nwg), dim3(512), 0, 0, out, cyc, iters, 1.f);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kx<F32, ROLES, NMW, NVW>), dim3(nwg), dim3(256 * (NMW + NVW)), 0, 0, out, cyc, iters, 1.f);
+        hipEventRecord(e1);
         hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
     }
-    hipMemcpy(hc, cyc, nwg * 8 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hc, cyc, nwg * 16 * 8, hipMemcpyDeviceToHost);
     double cm = 0, cv = 0;
     for (int i = 0; i < nwg; ++i)
-        for (int w = 0; w < 8; ++w) (w < 4 ? cm : cv) += hc[i * 8 + w];
-    cm /= nwg * 4; cv /= nwg * 4;
-    printf("%s %-44s: MFMA waves %6.1f cycles per MFMA, VALU waves %5.2f cycles per FMA\n", F32 ? "f32 " : "bf16", what,
-           (ROLES & 1) ? cm / (iters * 16.0) : 0.0, (ROLES & 2) ? cv / (iters * 64.0) : 0.0);
+        for (int w = 0; w < 4 * (NMW + NVW); ++w) (w < 4 * NMW ? cm : cv) += hc[i * 16 + w];
+    cm /= nwg * 4 * NMW; cv /= nwg * 4 * NVW;
+    const double fl = (ROLES & 1) ? (double)iters * 16 * (F32 ? 4096.0 : 32768.0) * 4 * NMW * nwg : 0.0;
+    printf("%s %-44s: MFMA waves %6.1f cycles per MFMA, VALU waves %5.2f cycles per FMA; kernel %.3f ms = %.0f TF/s of MFMAs\n", F32 ? "f32 " : "bf16", what,
+           (ROLES & 1) ? cm / (iters * 16.0) : 0.0, (ROLES & 2) ? cv / (iters * 64.0) : 0.0, ms, fl / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -353,12 +364,17 @@ int main() {
     runb<2, 16, 8>("chain of 4 then 16 VALU, 8 accumulators", 2, out, cyc);
     runb<2, 32, 8>("chain of 4 then 32 VALU, 8 accumulators", 2, out, cyc);
     runb<3, 32, 8>("32 VALU spread, 8 accumulators", 2, out, cyc);
-    hipFree(cyc); hipMalloc(&cyc, 256 * 8 * 8);
+    hipFree(cyc); hipMalloc(&cyc, 256 * 16 * 8);
+    hipFree(out); hipMalloc(&out, 256 * 1024 * 4);
     runx<1, 1>("MFMA waves alone", out, cyc);
     runx<1, 2>("VALU waves alone", out, cyc);
     runx<1, 3>("both: one MFMA wave + one VALU wave per SIMD", out, cyc);
     runx<0, 1>("MFMA waves alone", out, cyc);
     runx<0, 2>("VALU waves alone", out, cyc);
     runx<0, 3>("both: one MFMA wave + one VALU wave per SIMD", out, cyc);
+    // is the foreign-instruction budget per wave or per SIMD?  two VALU waves beside one MFMA wave (12 waves; assumes the hardware places
+    // wave w of a workgroup on SIMD w % 4, which the one + one results above support)
+    runx<1, 3, 1, 2>("one MFMA wave + TWO VALU waves per SIMD", out, cyc);
+    runx<0, 3, 1, 2>("one MFMA wave + TWO VALU waves per SIMD", out, cyc);
     return 0;
 }
