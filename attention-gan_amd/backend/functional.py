@@ -1005,9 +1005,12 @@ def _ids(class_ids, device) -> Optional[Tensor]:
 
 def _labels(labels, batch: int, device) -> Optional[Tensor]:
     """CE targets for the kernels (words_loss.py:98-99, sentence_loss.py:46-47): an int64 device vector, or None for arange(batch)
-    (the kernels' built-in default -- what train.py:104 / _make_match_labels builds, recognised by the `_agan_arange` tag so that
+    (the kernels' built-in default -- what train.py:104 / _make_match_labels builds, recognised by the `_agan_arange` tag = (batch, tensor version at tagging) so that
     the hot path neither copies nor reads the labels back)."""
-    if labels is None or getattr(labels, "_agan_arange", None) == batch:
+    if labels is None:
+        return None
+    tag = getattr(labels, "_agan_arange", None)
+    if tag is not None and tag == (batch, labels._version):      # still the untouched arange _make_match_labels built
         return None
     lab = torch.as_tensor(labels).reshape(-1)
     if lab.numel() != batch:

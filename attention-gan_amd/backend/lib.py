@@ -20,6 +20,7 @@ ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128    # include/agan.h: AGAN_COMM_ID_BYTES
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # include/agan.h: AGAN_DT_* (storage type of an activation tensor)
 AMAX_SLOT = 256        # floats per amax slot (include/agan.h: AGAN_AMAX_SLOT)
+ABI_VERSION = 101      # include/agan.h: AGAN_VERSION this binding was written against (argument lists changed between versions)
 
 
 class ConvGeom(Structure):
@@ -44,6 +45,12 @@ _SIGNATURES = {
     "agan_comm_destroy": (c_int, [_P]),
     "agan_allreduce_bucket": (c_int, [_P, _P, c_size_t, _P]),
     "agan_allreduce_chunk_elems": (c_size_t, [c_size_t, c_int]),
+    "agan_allreduce_scratch_bytes": (c_size_t, [c_size_t, c_int, c_int]),
+    "agan_allreduce_bucket_dt": (c_int, [_P, _P, c_size_t, c_int, _P, c_size_t, _P]),
+    "agan_exchange_wire_elems": (c_size_t, [c_size_t, c_int]),
+    "agan_exchange_pack_bf16": (c_int, [_P, _P, c_size_t, c_size_t, _P]),
+    "agan_exchange_sum_bf16": (c_int, [_P, c_int, c_size_t, _P, _P]),
+    "agan_exchange_unpack_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "agan_pack_job_blocks": (c_int, [c_int] * 5),
     "agan_pack_job_blocks_prec": (c_int, [c_int] * 6),
     "agan_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
@@ -120,6 +127,9 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
+    if lib.agan_version() != ABI_VERSION:
+        raise AganError(f"{LIB_PATH} reports C-ABI version {lib.agan_version()}, this binding is written against {ABI_VERSION} "
+                        f"(include/agan.h: argument lists differ between versions) -- rebuild with `make -C attention-gan_amd/csrc`")
     _lib = lib
     return lib
 

@@ -1156,6 +1156,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
     if (int e = check_geom(gg)) return e;
     AGAN_REQUIRE(x && dy && dw && ktable, "conv_wgrad: null pointer");
     AGAN_REQUIRE(prec == AGAN_PREC_F32 || prec_planes(prec) > 0, "conv_wgrad: unknown precision mode %d", prec);
+    const int prec_asked = prec;
     prec = agan_conv_wgrad_effective_prec(gg, pack_mode, prec);     // (callers may pass the mode that is set: fp32 operands either way)
     AGAN_REQUIRE(pack_mode == AGAN_PACK_FWD || pack_mode == AGAN_PACK_UP_FWD, "conv_wgrad: pack mode %d is not a forward mode", pack_mode);
     const Geom g = make_geom(gg);
@@ -1191,7 +1192,9 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
                 return AGAN_EWORKSPACE;
             }
             float* wsf = static_cast<float*>(ws);
-            AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
+            AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale),
+                         "conv_wgrad: precision mode %d runs this weight gradient as AGAN_PREC_F16X3 (agan_conv_wgrad_effective_prec), which needs the "
+                         "amax slots of x and dy (x_amax / dy_amax)", prec_asked);
             timer_begin(st);
             launch_rows_wgrad(x_v, dy_v, wsf, g, rp, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
             timer_end(st);
@@ -1222,7 +1225,9 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
         float* wsf = static_cast<float*>(ws);
         float* reduced = p.psplit > 1 ? wsf + p.slab * p.psplit : wsf;
         timer_begin(st);
-        AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale), "conv_wgrad: AGAN_PREC_F16X3 needs both agan_absmax_scale pairs");
+        AGAN_REQUIRE(prec != AGAN_PREC_F16X3 || (x_scale && dy_scale),
+                         "conv_wgrad: precision mode %d runs this weight gradient as AGAN_PREC_F16X3 (agan_conv_wgrad_effective_prec), which needs the "
+                         "amax slots of x and dy (x_amax / dy_amax)", prec_asked);
         launch_patch_wgrad(x_v, dy_v, wsf, g, pp, p, prec, st, x_scale, dy_scale, x_dtype != AGAN_DT_F32, dy_dtype != AGAN_DT_F32);
         timer_end(st);
         if (int e = check_launch("conv_wgrad/patch")) return e;

@@ -28,6 +28,19 @@ def rank_of(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
+def any_rank(flag: bool, group=None, device=None) -> bool:
+    """True on EVERY rank if `flag` is true on ANY rank: one MAX all-reduce of a single int32.  The data-parallel form of a
+    per-batch decision that changes the collectives a rank issues -- the reference's batch guard `if min(lengths) < 2 or
+    len(words) < BATCH_SIZE: continue` (train.py:112): a rank that skipped a step on its own would leave the others waiting in
+    the gradient all-reduce.  With one rank it is `bool(flag)`, no communication."""
+    if world_size(group) == 1:
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 @torch.no_grad()
 def sync_buffers_(module: torch.nn.Module, group=None) -> None:
     """Average the floating-point buffers (BatchNorm running statistics) over the replicas, in place; integer buffers
@@ -86,6 +99,7 @@ class DirectRccl:
         import ctypes
         from .backend import lib as L
         self.L = L
+        self.group = group
         rank, world = rank_of(group), world_size(group)
         ident = [None]
         if rank == 0:
@@ -121,9 +135,19 @@ class DirectRccl:
                 pass
         cls._shared.clear()
 
-    def all_reduce_(self, chunk: torch.Tensor, stream: torch.cuda.Stream) -> None:
+    def all_reduce_(self, chunk: torch.Tensor, stream: torch.cuda.Stream, bf16: bool = False) -> None:
+        """SUM all-reduce of one fp32 bucket on `stream`; bf16=True: 16-bit wire format, fp32 accumulation on arrival
+        (include/agan.h: agan_allreduce_bucket_dt with AGAN_DT_BF16 -- the same formula as all_reduce_bf16_)."""
         import ctypes
-        self.L.call("agan_allreduce_bucket", self.comm, ctypes.c_void_p(chunk.data_ptr()), chunk.numel(), ctypes.c_void_p(stream.cuda_stream))
+        if not bf16:
+            self.L.call("agan_allreduce_bucket", self.comm, ctypes.c_void_p(chunk.data_ptr()), chunk.numel(), ctypes.c_void_p(stream.cuda_stream))
+            return
+        world = world_size(self.group)
+        need = self.L.load().agan_allreduce_scratch_bytes(chunk.numel(), world, self.L.DT_BF16)
+        with torch.cuda.stream(stream):              # scratch from the caching allocator, owned by the comm stream
+            scratch = torch.empty(need, dtype=torch.uint8, device=chunk.device)
+        self.L.call("agan_allreduce_bucket_dt", self.comm, ctypes.c_void_p(chunk.data_ptr()), chunk.numel(), self.L.DT_BF16,
+                    ctypes.c_void_p(scratch.data_ptr()), need, ctypes.c_void_p(stream.cuda_stream))
 
     def close(self) -> None:
         if self.comm:
@@ -136,39 +160,52 @@ def all_reduce_bf16_(chunk: torch.Tensor, group=None) -> None:
     """SUM all-reduce of an fp32 gradient bucket that moves 16-bit values and ACCUMULATES IN FP32 on arrival (AGAN_DP_BF16=1):
     half the bytes of the fp32 reduce-scatter + all-gather on the per-link-bound xGMI rings.  In place, on the current stream.
 
-        1. every rank rounds its bucket to bf16;
-        2. all-to-all: rank j receives chunk j of every rank and sums the W pieces in rank order in fp32 (no bf16 accumulation: the
-           error does not grow with the number of ranks' additions);
-        3. the sums go back as bf16 (all-gather) and are widened:   result = fp32(bf16(sum_r fp32(bf16(g_r)))).
+        1. every rank rounds its bucket to bf16                                   (agan_exchange_pack_bf16);
+        2. all-to-all: rank j receives piece j of every rank and sums the W pieces in rank order in fp32, rounding once
+           (agan_exchange_sum_bf16: no bf16 accumulation, the error does not grow with the number of ranks' additions);
+        3. the sums go back as bf16 (all-gather) and are widened                  (agan_exchange_unpack_bf16):
+                   result = fp32(bf16(sum_r fp32(bf16(g_r)))).
 
     Two roundings of 2^-9 relative each -- far below the gradient noise of a 24-image batch; Adam's sign-like first steps do not see
-    it (tests: 2-rank step parity at 1e-3).  Backends without all-to-all (gloo on device tensors) take an all-gather of the whole
-    rounded bucket and form the same sums in the same order: identical values, more bytes -- that path exists for the tests."""
+    it (tests: 2-rank step parity at 1e-3).  On device tensors the three element-wise passes are HIP kernels behind the C ABI
+    (include/agan.h: agan_exchange_*; one launch each) and only the two collectives are torch.distributed's.  The plain-torch
+    branch below exists for the CPU tests (gloo has no all-to-all on these tensors: an all-gather of the whole rounded bucket, the
+    same sums in the same order -- identical values, more bytes)."""
     w = world_size(group)
     n = chunk.numel()
+    if chunk.is_cuda and n % 4 == 0 and chunk.data_ptr() % 16 == 0 and (w == 1 or dist.get_backend(group) == "nccl"):
+        import ctypes
+        from .backend import lib as L
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nw = L.load().agan_exchange_wire_elems(n, w)
+        per = nw // w
+        send = torch.empty(nw, dtype=torch.bfloat16, device=chunk.device)
+        L.call("agan_exchange_pack_bf16", ctypes.c_void_p(chunk.data_ptr()), ctypes.c_void_p(send.data_ptr()), n, nw, st)
+        if w > 1:
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+        else:
+            recv = send
+        mine = torch.empty(per, dtype=torch.bfloat16, device=chunk.device)
+        L.call("agan_exchange_sum_bf16", ctypes.c_void_p(recv.data_ptr()), w, per, ctypes.c_void_p(mine.data_ptr()), st)
+        if w > 1:
+            dist.all_gather_into_tensor(send, mine, group=group)          # the send image is free again: it receives the sums
+        else:
+            send = mine
+        L.call("agan_exchange_unpack_bf16", ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(chunk.data_ptr()), n, st)
+        return
     if w == 1:
         chunk.copy_(chunk.to(torch.bfloat16).float().to(torch.bfloat16).float())
         return
     per = (n + w - 1) // w
     send = torch.zeros(per * w, dtype=torch.bfloat16, device=chunk.device)
     send[:n].copy_(chunk)
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-        acc = recv.view(w, per)[0].float()
-        for r in range(1, w):                       # rank order, fp32
-            acc += recv.view(w, per)[r].float()
-        out = torch.empty(per * w, dtype=torch.bfloat16, device=chunk.device)
-        dist.all_gather_into_tensor(out, acc.to(torch.bfloat16), group=group)
-        chunk.copy_(out[:n])
-    else:
-        parts = [torch.empty_like(send) for _ in range(w)]
-        dist.all_gather(parts, send, group=group)
-        acc = parts[0].float()
-        for r in range(1, w):
-            acc += parts[r].float()
-        chunk.copy_(acc.to(torch.bfloat16)[:n])
+    parts = [torch.empty_like(send) for _ in range(w)]
+    dist.all_gather(parts, send, group=group)
+    acc = parts[0].float()
+    for r in range(1, w):                           # rank order, fp32
+        acc += parts[r].float()
+    chunk.copy_(acc.to(torch.bfloat16)[:n])
 
 
 class GradBuckets:
@@ -199,7 +236,12 @@ class GradBuckets:
         self.active = self.world > 1 or (os.environ.get("AGAN_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         # AGAN_DP_BF16=1: exchange 16-bit values with fp32 accumulation on arrival (all_reduce_bf16_) instead of the fp32 all-reduce
         self.bf16 = os.environ.get("AGAN_DP_BF16") == "1"
+        # AGAN_RCCL_DIRECT=1: the library's own communicator (agan_allreduce_bucket[_dt]) instead of torch.distributed's collectives;
+        # combined with AGAN_DP_BF16 it runs the 16-bit wire format on that communicator (grouped send/recv + all-gather)
         self.direct = DirectRccl.get(group) if (self.active and opt.flat.is_cuda and os.environ.get("AGAN_RCCL_DIRECT") == "1") else None
+        # optional measurement (bench.py): HIP events around every wait of a compute stream on the exchange -> exposed_ms()
+        self.measure = False
+        self._waits: List = []
         if self.active:
             if self.direct is not None:
                 self.comm_stream = self.direct.stream
@@ -243,7 +285,7 @@ class GradBuckets:
             HF.join_all_side_streams(self.comm_stream)          # weight gradients forked onto side streams
             if self.direct is not None:
                 chunk.record_stream(self.comm_stream)
-                self.direct.all_reduce_(chunk, self.comm_stream)      # joined in finish() through the comm stream
+                self.direct.all_reduce_(chunk, self.comm_stream, self.bf16)      # joined in finish() through the comm stream
                 return
             if os.environ.get("AGAN_DP_STUB") == "1":          # (measurement knob: the stream choreography without the collective)
                 return
@@ -271,7 +313,7 @@ class GradBuckets:
         for s, e in self.bounds:
             chunk = self.opt.grad[s:e]
             if self.direct is not None:
-                self.direct.all_reduce_(chunk, self.comm_stream)
+                self.direct.all_reduce_(chunk, self.comm_stream, self.bf16)
             elif self.comm_stream is not None:
                 with torch.cuda.stream(self.comm_stream):
                     if self.bf16:
@@ -282,11 +324,41 @@ class GradBuckets:
                 all_reduce_bf16_(chunk, self.group)
             else:
                 handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._join(cur, handles)
+        return 1.0 / self.world
+
+    @property
+    def mode(self) -> str:
+        """what moves the buckets: for the bench line / logs"""
+        if not self.active:
+            return "none (one rank)"
+        wire = "bf16 wire, fp32 accumulate" if self.bf16 else "fp32"
+        how = "agan_allreduce_bucket (library communicator: reduce-scatter + all-gather)" if self.direct is not None else \
+              ("torch.distributed all_to_all + all_gather" if self.bf16 else "torch.distributed all_reduce")
+        return f"{how}, {wire}"
+
+    def _join(self, cur, handles) -> None:
+        """the compute stream `cur` waits for the exchange (async handles: Work.wait() makes the CURRENT stream wait for the
+        collective; then the comm stream itself); with `measure` on, two events bracket the waits -- their distance is the time the
+        stream sat blocked = EXPOSED communication, nothing else being queued between them"""
+        measure = self.measure and cur is not None
+        if measure:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(cur)
         for h in handles:
             h.wait()
         if self.comm_stream is not None:
             cur.wait_stream(self.comm_stream)
-        return 1.0 / self.world
+        if measure:
+            b.record(cur)
+            self._waits.append((a, b))
+
+    def exposed_ms(self) -> float:
+        """sum of the measured waits since the last call (synchronises the device)"""
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._waits)
+        self._waits = []
+        return total
 
     def finish(self) -> float:
         """Join outstanding exchanges; returns the scale the optimiser must apply (1/world_size)."""
@@ -298,9 +370,6 @@ class GradBuckets:
             if self._armed and left > 0:
                 self._pending[b] = 0
                 self._launch(b)
-        for h in self._handles:
-            h.wait()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._join(torch.cuda.current_stream() if self.opt.flat.is_cuda else None, self._handles)
         self._handles, self._armed = [], False
         return 1.0 / self.world

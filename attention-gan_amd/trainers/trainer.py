@@ -12,7 +12,7 @@ from torch import Tensor
 from torch.nn import Module
 
 from ..backend import functional as HF
-from ..dataparallel import GradBuckets, averaged_buffers, broadcast_module_, rank_of, world_size
+from ..dataparallel import GradBuckets, any_rank, averaged_buffers, broadcast_module_, rank_of, world_size
 from ..losses.disc_loss import NonSaturatingDiscLoss
 from ..losses.gen_loss import NonSaturatingGenLoss
 from ..losses.KL_loss import KL_loss
@@ -33,7 +33,9 @@ class ModelTrainer:
 
     def _make_match_labels(self, batch_size: int) -> Tensor:
         labels = torch.arange(batch_size, dtype=torch.int64, device=_device())
-        labels._agan_arange = batch_size          # lets the DAMSM losses use the kernels' built-in arange targets (no copy, no readback)
+        # lets the DAMSM losses use the kernels' built-in arange targets (no copy, no readback); the tag carries the tensor's version
+        # counter, so an in-place edit of the labels (labels[i] = j, labels.copy_(perm)) voids it and the values travel as given
+        labels._agan_arange = (batch_size, labels._version)
         return labels
 
     def _count_parameters(self, model: Module):
@@ -62,9 +64,38 @@ class ModelTrainer:
         return [self._denormalise_single(t) for t in tensors]
 
     def _plot_history(self, *args, **kwargs) -> None:
-        raise NotImplementedError("plotting is outside the hot-path scope (SURVEY.md section 2 #7): use the reference's helpers on CPU")
+        raise NotImplementedError("loss-curve plotting is outside the hot-path scope (SURVEY.md section 2 #7): the histories are "
+                                  "plain lists of device scalars (g_losses, d_losses, damsm_losses)")
 
-    _plot_image_grid = _plot_history
+    def _image_grid(self, fake_images: List[Tensor]) -> List[Tensor]:
+        """The reference's evaluation grid (trainers/trainer.py:68-98) as TENSORS: per resolution the first n*n images (n*n = the
+        largest square number <= the batch, :76-78) tiled row-major into one [3, n*res, n*res] uint8 image (values clamped to [0, 1]
+        like imshow does for float data).  No matplotlib: the caller decides where pixels go."""
+        num = len(fake_images[0])
+        square = next((i for i in range(num, 0, -1) if math.isqrt(i) ** 2 == i), 1)
+        n = math.isqrt(square)
+        grids = []
+        for images in fake_images:
+            c, h, w = images.shape[1:]
+            g = images[:square].detach().float().clamp(0.0, 1.0).reshape(n, n, c, h, w).permute(2, 0, 3, 1, 4).reshape(c, n * h, n * w)
+            grids.append((g * 255.0 + 0.5).to(torch.uint8))
+        return grids
+
+    def _plot_image_grid(self, fake_images: List[Tensor], epoch: Optional[int] = None, folder: str = 'generated_images') -> List[str]:
+        """_image_grid written to {folder}/epoch_{e}-{res}x{res}.ppm (binary PPM: the reference writes PNGs through matplotlib,
+        trainers/trainer.py:93-98; same file stems).  Returns the paths."""
+        os.makedirs(folder, exist_ok=True)
+        paths = []
+        for g, images in zip(self._image_grid(fake_images), fake_images):
+            res = images.shape[-1]
+            stem = f"epoch_{epoch}-{res}x{res}" if epoch else f"_{res}x{res}"
+            path = f"{folder}/{stem}.ppm"
+            hwc = g.permute(1, 2, 0).contiguous().cpu().numpy()
+            with open(path, "wb") as f:
+                f.write(f"P6\n{hwc.shape[1]} {hwc.shape[0]}\n255\n".encode())
+                f.write(hwc.tobytes())
+            paths.append(path)
+        return paths
 
     def _save_weights(self, modules: List, root_folder='saved_weights') -> None:
         """state_dict per module at {root}/{ClassName}.pkl.  Optimisers get an index suffix so that the reference's
@@ -408,19 +439,49 @@ class GanTrainStep(ModelTrainer):
         """Checkpoint of the whole step: weights, BatchNorm buffers, the four optimisers and the noise generators' states (so a
         resumed run continues the z / eps sequence instead of replaying it from the seed).
 
-        Under torch.distributed the BatchNorm running statistics are per replica (local batches, as in the reference's
-        single-process BN).  With `all_ranks=True` (default) the checkpoint holds their MEAN over the ranks, so every rank
-        writes the same file -- this is a COLLECTIVE: every rank of the group must call state_dict(), a lone
-        `if rank == 0: save(step.state_dict())` would hang.  For that pattern pass `all_ranks=False`: no communication, the
-        calling rank's own statistics are saved.  The live buffers are never modified either way."""
+        Under torch.distributed two things are PER REPLICA: the BatchNorm running statistics (local batches, as in the reference's
+        single-process BN) and the noise generators (seeded seed * 1000003 + rank, so that replicas draw different z / eps).  With
+        `all_ranks=True` (default) the checkpoint holds the MEAN of the running statistics over the ranks and the generator state of
+        EVERY rank (`rng` / `sample_rng` = {rank: state}), so every rank writes the same file -- this is a COLLECTIVE: every rank of
+        the group must call state_dict(), a lone `if rank == 0: save(step.state_dict())` would hang.  For that pattern pass
+        `all_ranks=False`: no communication, the calling rank's own statistics and its own generator states ({rank: state} with one
+        entry) are saved.  The live buffers and generators are never modified either way."""
+        mine = {"rng": self.rng.get_state(), "sample_rng": self.sample_rng.get_state()}
+        w = world_size(self.group)
         sd = {"generator": self.G.state_dict(), "discriminators": [d.state_dict() for d in self.Ds],
               "g_optim": self.g_opt.state_dict(), "d_optims": [o.state_dict() for o in self.d_opts],
-              "rng": self.rng.get_state(), "sample_rng": self.sample_rng.get_state()}
-        if all_ranks and world_size(self.group) > 1:
+              "rng": {self.rank: mine["rng"]}, "sample_rng": {self.rank: mine["sample_rng"]}, "rng_world": w}
+        if all_ranks and w > 1:
+            import torch.distributed as dist
             for m, msd in zip([self.G] + self.Ds, [sd["generator"]] + sd["discriminators"]):
                 for k, v in averaged_buffers(m, self.group).items():
                     msd[k] = v
+            gathered = [None] * w
+            dist.all_gather_object(gathered, mine, group=self.group)
+            for key in ("rng", "sample_rng"):
+                sd[key] = {r: gathered[r][key].cpu() for r in range(w)}
         return sd
+
+    @staticmethod
+    def _restore_generator(gen: torch.Generator, saved, rank: int) -> None:
+        """Put `gen` where rank `rank` of the checkpointed run left it.  `saved` is {rank: state} (or, from checkpoints written before
+        the states were keyed by rank, one bare state = the saving rank's, by convention rank 0).  A rank the checkpoint has no state
+        for (rank-0-only save, or a resume on more ranks) gets a state DERIVED from the saved one and its rank -- deterministic, and
+        different on every rank, which is what the per-rank seeds are for (identical z / eps on all replicas would collapse the
+        effective noise batch to one shard's)."""
+        import hashlib
+        if isinstance(saved, dict):
+            if rank in saved:
+                gen.set_state(saved[rank].cpu())
+                return
+            base = saved[min(saved)]
+        else:
+            if rank == 0:
+                gen.set_state(saved.cpu())
+                return
+            base = saved
+        digest = hashlib.sha256(base.cpu().numpy().tobytes() + int(rank).to_bytes(8, "little")).digest()
+        gen.manual_seed(int.from_bytes(digest[:8], "little") & ((1 << 63) - 1))
 
     def load_state_dict(self, sd: Dict) -> None:
         self.G.load_state_dict(sd["generator"])
@@ -428,26 +489,62 @@ class GanTrainStep(ModelTrainer):
         for d, o, ds, os_ in zip(self.Ds, self.d_opts, sd["discriminators"], sd["d_optims"]):
             d.load_state_dict(ds)
             o.load_state_dict(os_)
-        # noise streams (checkpoints written before these were saved simply restart them from the seed)
+        # noise streams, per rank (checkpoints written before these were saved simply restart them from the seed)
         for key, gen in (("rng", self.rng), ("sample_rng", self.sample_rng)):
             if sd.get(key) is not None:
-                gen.set_state(sd[key].cpu())
+                self._restore_generator(gen, sd[key], self.rank)
 
     @torch.no_grad()
-    def generate_images(self, word_embs: Tensor, sent_embs: Tensor, lengths, noise: Optional[Tensor] = None) -> List[Tensor]:
-        """Sampling path of train.py:154-158 / test.py:77-87: eval-mode generator forward (running BatchNorm statistics),
-        images mapped from [-1,1] to [0,1].  Same kernels as training, forward only."""
+    def generate_images(self, word_embs: Tensor, sent_embs: Tensor, lengths, noise: Optional[Tensor] = None,
+                        train_mode_bn: bool = False, eps: Optional[Tensor] = None) -> List[Tensor]:
+        """Sampling path; images mapped from [-1,1] to [0,1].  Same kernels as training, forward only.
+
+        train_mode_bn=False (default): test.py:77-87 -- eval-mode generator (running BatchNorm statistics).
+        train_mode_bn=True: the EPOCH-END sample exactly as train.py:154-158 takes it -- under no_grad but WITHOUT .eval(): every
+        BatchNorm normalises with the statistics of this batch and pushes them into its running statistics (one more update per
+        epoch, which the next checkpoint carries), `noise` is the fixed input of train.py:105."""
         was_training = self.G.training
-        self.G.eval()
+        self.G.train(bool(train_mode_bn))
         try:
             b = word_embs.shape[0]
             if noise is None:
                 noise = torch.randn(b, self.G.z_dim, dtype=torch.float32, device=word_embs.device, generator=self.sample_rng)
-            eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.sample_rng)
+            if eps is None:
+                eps = torch.randn(b, self.G.cond_dim, dtype=torch.float32, device=word_embs.device, generator=self.sample_rng)
             fakes, _, _, _ = self.G(noise, sent_embs, word_embs, self._make_mask(lengths, word_embs.shape[2]), eps)
             return self._denormalise_multiple(fakes)
         finally:
             self.G.train(was_training)
+
+    # -- the loop around the step (train.py:107-158) -------------------------------------------------------------------
+    def skip_batch(self, lengths, batch_rows: int, batch_size: int) -> bool:
+        """The reference's batch guard (train.py:112: `if min(lengths) < 2 or len(words) < BATCH_SIZE: continue`), decided for the
+        whole data-parallel group: a rank that skipped on its own would leave the others waiting in the gradient all-reduce, so
+        every rank contributes its local verdict to ONE small MAX all-reduce and all skip together if any shard fails the guard
+        (dataparallel.any_rank).  A collective under torch.distributed: every rank calls it once per batch, in step."""
+        lens = lengths.tolist() if hasattr(lengths, "tolist") else list(lengths)
+        local = (min(int(v) for v in lens) < 2) if len(lens) else True
+        local = local or int(batch_rows) < int(batch_size)
+        return any_rank(local, self.group, next(self.G.parameters()).device)
+
+    def train_epoch(self, batches, text_encoder: Callable, batch_size: int, max_batches: Optional[int] = None) -> int:
+        """One pass over `batches` (tuples in the reference's wire format, data/bedrooms.py:229-236: words, lengths, class_ids,
+        img64, img128, img256) as train.py:109-151 runs it: guard (skip_batch), frozen text encoder, step().  Under data parallelism
+        every rank iterates ITS shard of the data with the same number of batches.  Returns the number of steps taken."""
+        dev = next(self.G.parameters()).device
+        steps = 0
+        for n, batch in enumerate(batches):
+            if max_batches is not None and n >= max_batches:
+                break
+            words, lengths, class_ids, img64, img128, img256 = batch
+            if self.skip_batch(lengths, len(words), batch_size):
+                continue
+            with torch.no_grad():
+                word_embs, sent_embs = text_encoder(words.to(dev), lengths)
+            cids = class_ids.detach().cpu().numpy() if isinstance(class_ids, Tensor) else class_ids      # train.py:114
+            self.step(word_embs.contiguous(), sent_embs.contiguous(), lengths, cids, [img64.to(dev), img128.to(dev), img256.to(dev)])
+            steps += 1
+        return steps
 
 
 class GraphedStep:

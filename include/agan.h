@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define AGAN_VERSION 100 /* 0.1.0 */
+#define AGAN_VERSION 101 /* 0.1.1 */
+/* 101 (round 4): agan_words_loss_fwd / agan_sent_loss_fwd carry `labels` after class_ids (added in place during round 3 without a
+ * version change: a caller built against the 100 header must be rebuilt -- bind by version, backend/lib.py asserts it);
+ * agan_allreduce_bucket_dt + agan_exchange_* (16-bit wire format of the gradient exchange); amax slots of agan_conv_wgrad are
+ * needed whenever agan_conv_wgrad_effective_prec says AGAN_PREC_F16X3, which includes AGAN_PREC_BF16X6 callers. */
 
 enum {
     AGAN_OK = 0,
@@ -162,9 +166,12 @@ int agan_absmax(const float* x, size_t n, float* amax_slot, void* stream);
  * Replaces the wgrad half of conv2d backward at the same call sites. */
 size_t agan_conv_wgrad_ws_bytes(const agan_conv_geom* g);
 /* accumulate != 0: dw += gradient (a parameter used twice in one backward, e.g. D on the real and the fake batch). */
+/* x_amax / dy_amax: the amax slots of x and dy, REQUIRED whenever agan_conv_wgrad_effective_prec(g, pack_mode, prec) returns
+ * AGAN_PREC_F16X3 -- that is prec == AGAN_PREC_F16X3 and also prec == AGAN_PREC_BF16X6, whose weight gradients run as two-plane
+ * fp16 splits on the row-resident kernel (csrc/conv_wgrows.hip); NULL in every other mode. */
 int agan_conv_wgrad(const float* x, const float* dy, float* dw, const agan_conv_geom* g, const int32_t* ktable, int pack_mode,
                     int kh, int kw, int prec, int accumulate, void* ws, size_t ws_bytes, void* stream,
-                    const float* x_amax, const float* dy_amax /* AGAN_PREC_F16X3: amax slots of x and dy; NULL otherwise */);
+                    const float* x_amax, const float* dy_amax);
 
 /* the same with typed activation storage (x: x_dtype, dy: dy_dtype; dw stays fp32): 16-bit tensors where
  * agan_conv_wgrad_dt_supported says 1 -- the one-plane patch weight gradient of the matching precision mode */
@@ -332,6 +339,23 @@ int agan_comm_unique_id(void* id);
 int agan_comm_init(void** comm, int rank, int world, const void* id);
 int agan_comm_destroy(void* comm);
 int agan_allreduce_bucket(void* comm, float* buf, size_t n, void* stream);
+/* The same exchange with a WIRE dtype (SURVEY.md section 8b's `agan_allreduce_bucket(buf, n, dtype, comm, stream)`):
+ * AGAN_DT_F32 = the call above; AGAN_DT_BF16 = the bucket travels as bf16 and is ACCUMULATED IN FP32 on arrival:
+ * round (agan_exchange_pack_bf16) -> all-to-all of the `world` pieces (grouped send/recv) -> rank-ordered fp32 sum of the pieces a
+ * rank owns, rounded once (agan_exchange_sum_bf16) -> all-gather of the sums -> widen (agan_exchange_unpack_bf16):
+ *     buf = fp32(bf16(sum_r fp32(bf16(buf_r)))), identical on every rank, half the bytes of the fp32 exchange on every link.
+ * n must be a multiple of 4; `scratch` = agan_allreduce_scratch_bytes(n, world, dtype) bytes of device memory (0 for AGAN_DT_F32). */
+size_t agan_allreduce_scratch_bytes(size_t n, int world, int wire_dtype);
+int agan_allreduce_bucket_dt(void* comm, float* buf, size_t n, int wire_dtype, void* scratch, size_t scratch_bytes, void* stream);
+/* The three element-wise passes of the 16-bit wire format on their own (a host that moves the bytes itself -- torch.distributed's
+ * all_to_all_single / all_gather_into_tensor in dataparallel.all_reduce_bf16_ -- uses them around its collectives).  16 bytes per
+ * lane, HBM-bound.  agan_exchange_wire_elems(n, world) = elements of the wire image: `world` equal pieces, each a multiple of 8
+ * elements (piece r = elements [r*per, (r+1)*per) of the zero-padded bucket).  n and per are multiples of 4. */
+size_t agan_exchange_wire_elems(size_t n, int world);
+int agan_exchange_pack_bf16(const float* g, void* wire, size_t n, size_t n_wire, void* stream);
+int agan_exchange_sum_bf16(const void* pieces /* [world][per] bf16, piece r from rank r */, int world, size_t per,
+                           void* sum /* [per] bf16 */, void* stream);
+int agan_exchange_unpack_bf16(const void* wire, float* g, size_t n, void* stream);
 /* the reduce-scatter / all-gather chunk of a bucket of n floats over `world` ranks (rank r owns elements [r*chunk, (r+1)*chunk));
  * 0 = the bucket does not split into 16-byte aligned equal chunks and goes out as one library all-reduce.  Pure host arithmetic. */
 size_t agan_allreduce_chunk_elems(size_t n, int world);

@@ -55,6 +55,36 @@ def free_port() -> int:
         return sock.getsockname()[1]
 
 
+def collect_from_children(q, procs, n=None, timeout=300.0, poll=0.5):
+    """`n` results (default: one per process) from the queue the child processes report into -- WATCHING the children: a child that
+    died without reporting (a crash in native code, an assertion in the worker) fails the test within `poll` seconds with its exit
+    code, instead of after the whole queue timeout (a dead child used to cost five minutes of the GPU-test budget)."""
+    import queue as _queue
+    import time
+    want = len(procs) if n is None else n
+    got, t0 = [], time.monotonic()
+    while len(got) < want:
+        try:
+            got.append(q.get(timeout=poll))
+            continue
+        except _queue.Empty:
+            pass
+        dead = [p for p in procs if p.exitcode not in (None, 0)]
+        if dead:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f"child process died with exit code {dead[0].exitcode} before reporting ({len(got)} of {want} results in)")
+        if all(p.exitcode == 0 for p in procs) and q.empty():
+            raise AssertionError(f"every child exited cleanly but only {len(got)} of {want} results arrived")
+        if time.monotonic() - t0 > timeout:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f"timed out after {timeout:.0f} s waiting for the child processes ({len(got)} of {want} results in)")
+    return got
+
+
 class LeakyMaskRecorder:
     """Records, in call order, the branch every LeakyReLU of the HIP path took (sign of its output), per discriminator call.
 

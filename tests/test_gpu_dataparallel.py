@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from helpers import free_port
+from helpers import collect_from_children, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -81,7 +81,7 @@ def test_two_rank_step_equals_mean_of_shard_gradients(bf16):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bf16)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    got = sorted(collect_from_children(q, procs), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -195,7 +195,7 @@ def test_one_rank_nccl_exchange_is_identity():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_one_rank_worker, args=(free_port(), q))
     p.start()
-    g_sd, g_total = q.get(timeout=300)
+    (g_sd, g_total), = collect_from_children(q, [p])
     p.join(60)
     assert p.exitcode == 0
     # the same two steps without torch.distributed: bitwise the same weights (the exchange added nothing and reordered nothing)
@@ -240,7 +240,7 @@ def test_one_rank_direct_rccl_exchange_is_identity():
     q = ctx.Queue()
     p = ctx.Process(target=_direct_rccl_worker, args=(free_port(), q))
     p.start()
-    g_sd, g_total = q.get(timeout=300)
+    (g_sd, g_total), = collect_from_children(q, [p])
     p.join(60)
     assert p.exitcode == 0
     dev = torch.device("cuda", 0)
@@ -295,7 +295,7 @@ def test_segmented_graphs_equal_eager_steps(force_dp):
     q = ctx.Queue()
     p = ctx.Process(target=_segmented_worker, args=(free_port(), q, force_dp))
     p.start()
-    g_sd, d_sds, g_total, d_loss2 = q.get(timeout=300)
+    (g_sd, d_sds, g_total, d_loss2), = collect_from_children(q, [p])
     p.join(60)
     assert p.exitcode == 0
     dev = torch.device("cuda", 0)
@@ -311,3 +311,85 @@ def test_segmented_graphs_equal_eager_steps(force_dp):
     for d, sd in zip(Ds, d_sds):
         for k, v in d.state_dict().items():
             assert np.array_equal(v.detach().cpu().numpy(), sd[k]), k
+
+
+def test_bf16_exchange_kernels_match_the_formula():
+    """The three element-wise passes of the 16-bit wire format through the C ABI (include/agan.h: agan_exchange_*):
+    pack = bf16(g) zero-padded to `world` equal pieces; sum = bf16 of the rank-ordered fp32 sum of the pieces; unpack = widen --
+    bit for bit the arithmetic dataparallel.all_reduce_bf16_ documents, for 1..8 ranks' worth of pieces."""
+    import ctypes
+    L = importlib.import_module("attention-gan_amd.backend.lib")
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(4)
+    for world in (1, 2, 3, 8):
+        for n in (4, 1000, 65536 + 12, 7_084_592):
+            nw = lib.agan_exchange_wire_elems(n, world)
+            per = nw // world
+            assert nw >= n and per * world == nw and per % 8 == 0 and nw - n < 8 * world + world
+            grads = [(torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 3, (1,), generator=g))).to(dev) for _ in range(world)]
+            wires = []
+            for gr in grads:
+                w = torch.full((nw,), float("nan"), dtype=torch.bfloat16, device=dev)
+                L.call("agan_exchange_pack_bf16", p(gr), p(w), n, nw, st)
+                assert torch.equal(w[:n], gr.to(torch.bfloat16)) and float(w[n:].float().abs().sum()) == 0.0
+                wires.append(w)
+            # what rank j receives: piece j of every rank, stacked in rank order; all ranks' sums, gathered, are the whole bucket
+            gathered = torch.empty(nw, dtype=torch.bfloat16, device=dev)
+            for j in range(world):
+                pieces = torch.stack([wires[r][j * per:(j + 1) * per] for r in range(world)]).contiguous()
+                L.call("agan_exchange_sum_bf16", p(pieces), world, per, p(gathered[j * per:(j + 1) * per]), st)
+            out = torch.empty(n, device=dev)
+            L.call("agan_exchange_unpack_bf16", p(gathered), p(out), n, st)
+            acc = grads[0].to(torch.bfloat16).float()
+            for r in range(1, world):
+                acc = acc + grads[r].to(torch.bfloat16).float()
+            assert torch.equal(out, acc.to(torch.bfloat16).float()), (world, n)
+
+
+def _direct_bf16_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AGAN_DP_FORCE="1", AGAN_RCCL_DIRECT="1", AGAN_DP_BF16="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        DP = importlib.import_module("attention-gan_amd.dataparallel")
+        net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 32)).to(dev)
+        opt = OPT.FlatAdam(net.parameters())
+        bk = DP.GradBuckets(opt, bucket_bytes=16 << 10)
+        assert bk.direct is not None and bk.bf16 and "bf16 wire" in bk.mode and len(bk.bounds) > 1
+        opt.zero_grad()
+        bk.arm()
+        net(torch.randn(8, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))).pow(2).sum().backward()
+        before = None
+        scale = bk.finish()
+        torch.cuda.synchronize()
+        exchanged = opt.grad.clone()
+        # the same gradients without any exchange
+        opt.zero_grad()
+        net(torch.randn(8, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))).pow(2).sum().backward()
+        opt._rebind()
+        torch.cuda.synchronize()
+        q.put((scale, exchanged.cpu().numpy(), opt.grad.clone().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_direct_rccl_bf16_exchange_rounds_once():
+    """AGAN_RCCL_DIRECT=1 + AGAN_DP_BF16=1 (the pair used to fall back to the fp32 exchange silently): the 16-bit wire
+    format on the library's own communicator -- pack, grouped send/recv (to itself with one rank), rank-ordered sum, all-gather,
+    unpack.  With one rank the result is the bucket rounded to bf16: fp32(bf16(g))."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_direct_bf16_worker, args=(free_port(), q))
+    p.start()
+    (scale, exchanged, plain), = collect_from_children(q, [p])
+    p.join(60)
+    assert p.exitcode == 0 and scale == 1.0
+    want = torch.from_numpy(plain).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(exchanged, want) and not np.array_equal(exchanged, plain)

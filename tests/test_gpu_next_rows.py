@@ -59,6 +59,32 @@ def test_sampling_path_matches_oracle_eval_mode():
     assert_close(mu_d, mu, RTOL, "mu")
 
 
+def test_epoch_end_sample_is_train_mode_batchnorm_under_no_grad():
+    """train.py:154-158: the epoch-end sample runs the generator under no_grad WITHOUT .eval() on the fixed noise of :105 -- every
+    BatchNorm normalises with THIS batch's statistics and pushes them into its running statistics once more.
+    generate_images(train_mode_bn=True) against the oracle's train-mode forward: images, and the running statistics afterwards."""
+    G, Ds, enc, d = _setup()
+    step = TR.GanTrainStep(G, Ds, enc)
+    _one(step, d)
+    gp = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    fixed = torch.randn(d["noise"].shape, generator=torch.Generator().manual_seed(11)).to(DEV)       # fixed_input, train.py:105
+    imgs = step.generate_images(d["words"], d["sent"], d["lens"], fixed, train_mode_bn=True, eps=d["eps"])
+    assert G.training and all(not t.requires_grad for t in imgs)
+    ref, _, _, _ = O.generator_forward(gp, fixed.cpu(), d["sent"].cpu(), d["words"].cpu(), O.make_mask(d["lens"]), d["eps"].cpu(), train=True)
+    for i in range(3):
+        assert_close(imgs[i], ref[i] * 0.5 + 0.5, RTOL, f"train-mode sample {i}")            # _denormalise_multiple
+    after = G.state_dict()
+    moved = 0
+    for k, v in gp.items():                                    # the oracle updated gp's running statistics in place
+        if "running" in k or "num_batches" in k:
+            assert_close(after[k].float(), v.float(), RTOL, k)
+            moved += 1
+    assert moved > 0
+    # and it differs from the eval-mode sample (running statistics) -- the two modes are not interchangeable
+    ev = step.generate_images(d["words"], d["sent"], d["lens"], fixed, eps=d["eps"])
+    assert float((ev[2] - imgs[2]).abs().max()) > 1e-3
+
+
 def test_checkpoint_resume_reproduces_next_step():
     G, Ds, enc, d = _setup(7)
     a = TR.GanTrainStep(G, Ds, enc)
@@ -110,21 +136,42 @@ def test_checkpoint_resume_continues_the_noise_stream():
     assert not torch.equal(out_a["fake_imgs"][2], out_c["fake_imgs"][2])
 
 
-def test_damsm_pretrain_step():
-    """pretrain_damsm.py:114-134 with the stock encoders: the HIP losses equal the oracle's on the same encoder outputs; the RNN
-    gradient is clipped to a total norm of 0.25 (:132); and the post-step weights of both encoders equal torch.optim.Adam(2e-3,
-    (0.5, 0.999)) applied on the CPU to the ORACLE's gradients after the same clip."""
+class _FixedDropout(torch.nn.Module):
+    """nn.Dropout(p) in training mode with the keep-mask SUPPLIED (inverted dropout: x * keep / (1 - p)), so that the device run and
+    the CPU reference run drop the same embedding elements (the stock module draws its mask from a device-specific RNG stream)"""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.register_buffer("keep", keep)
+        self.p = p
+
+    def forward(self, x):
+        return x * self.keep.to(x.dtype) / (1.0 - self.p)
+
+
+@pytest.mark.parametrize("dropout", [False, True], ids=["dropout-off", "dropout-0.5-fixed-mask"])
+def test_damsm_pretrain_step(dropout):
+    """BASELINE configs[0] as written -- pretrain_damsm.py:114-134 on 4 synthetic 64x64 images + 10-token captions (lengths 10, 7, 2,
+    10: a full one and the shortest the batch guard lets through) -- with the stock encoders: the HIP losses equal the oracle's on the
+    same encoder outputs; the RNN gradient is clipped to a total norm of 0.25 (:132); and the post-step weights of both encoders equal
+    torch.optim.Adam(2e-3, (0.5, 0.999)) applied on the CPU to the ORACLE's gradients after the same clip.  Second case: the
+    embedding dropout of rnn_encoder.py:83 ACTIVE (p = 0.5, pretrain_damsm.py:66 builds the encoder with its default) with one
+    seeded keep-mask handed to both sides."""
     import copy
     torch.manual_seed(3)
-    B, Tn, emb, vocab = 4, 6, 32, 50
-    rnn = RNN.RNNEncoder(vocab, embdim=24, dropprob=0.0, nhidden=emb).to(DEV)   # dropout off: the oracle must see the same embeddings
+    B, Tn, emb, vocab = 4, 10, 32, 50
+    rnn = RNN.RNNEncoder(vocab, embdim=24, dropprob=0.0, nhidden=emb).to(DEV)   # (the stock dropout is replaced below when it is on)
     cnn = ENC.StandInImageEncoder(emb).to(DEV)                  # the Inception-shaped trunk obeys the same contract (test below)
     rnn.train()                                                 # (MIOpen's LSTM backward needs training mode)
     rnn_c, cnn_c = copy.deepcopy(rnn).cpu(), copy.deepcopy(cnn).cpu()
-    step = TR.DAMSMTrainStep(rnn, cnn)
     g = torch.Generator().manual_seed(3)
+    if dropout:
+        keep = (torch.rand(B, Tn, 24, generator=g) >= 0.5)
+        assert 0.3 < float(keep.float().mean()) < 0.7
+        rnn.dropout, rnn_c.dropout = _FixedDropout(keep.to(DEV), 0.5), _FixedDropout(keep, 0.5)
+    step = TR.DAMSMTrainStep(rnn, cnn)
     caps = torch.randint(0, vocab, (B, Tn), generator=g)
-    lens = torch.tensor([6, 4, 2, 5])
+    lens = torch.tensor([10, 7, 2, 10])
     img = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
     out = step.step(caps.to(DEV), lens, None, img.to(DEV))
     # ---- the same step on the CPU: stock encoders, ORACLE losses, torch's clip and Adam ----

@@ -672,10 +672,16 @@ def test_damsm_losses_honour_labels():
         for got, want, what in ((fd, fr, "dfeat"), (wd, wr, "dwemb"), (cd, cr, "dcode"), (sd, sr, "dsemb")):
             assert_close(got.grad, want.grad, RTOL, what)
     tagged = TRN.ModelTrainer()._make_match_labels(B)
-    assert getattr(tagged, "_agan_arange", None) == B
+    assert getattr(tagged, "_agan_arange", None) == (B, tagged._version)
     a, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), tagged, lens, None)
     b, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.arange(B, device=DEV), lens, None)
     assert torch.equal(a, b)
+    # an in-place edit of the tagged tensor voids the tag: the kernels then see the tensor's VALUES, like CrossEntropyLoss
+    perm = torch.tensor([2, 0, 1, 5, 3, 4], device=DEV)
+    tagged.copy_(perm)
+    c, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), tagged, lens, None)
+    d, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), perm.clone(), lens, None)
+    assert torch.equal(c, d) and not torch.equal(c, a)
     with pytest.raises(ValueError):
         WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.arange(B - 1, device=DEV), lens, None)
     bad, _ = WL(torch.device(DEV)).get_loss(feat.to(DEV), wemb.to(DEV), torch.tensor([0, 1, 2, 3, 4, B], device=DEV), lens, None)
