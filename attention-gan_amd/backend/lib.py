@@ -40,6 +40,7 @@ _SIGNATURES = {
     "agan_timer_destroy": (c_int, [_P]),
     "agan_timer_arm": (c_int, [_P, _P]),
     "agan_timer_elapsed_ms": (c_int, [_P, _P, _P]),
+    "agan_timer_last_kernel": (c_int, [_P, c_size_t]),
     "agan_comm_unique_id": (c_int, [_P]),
     "agan_comm_init": (c_int, [_P, c_int, c_int, _P]),
     "agan_comm_destroy": (c_int, [_P]),

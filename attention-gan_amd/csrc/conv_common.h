@@ -10,6 +10,16 @@ namespace conv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Every kernel launch of the conv engine goes through AGAN_LAUNCH, which remembers the host stub of the kernel it launched (thread-local):
+// the measurement hook (agan_timer_arm / agan_timer_last_kernel, conv.hip) can then NAME the kernel a timed call ran -- the demangled
+// symbol, exactly as `rocprofv3 --kernel-trace --stats` prints it -- instead of the caller guessing a label.
+extern thread_local const void* g_noted_kernel;
+#define AGAN_LAUNCH(kernel, ...)                                                   \
+    do {                                                                           \
+        ::agan::conv::g_noted_kernel = reinterpret_cast<const void*>(kernel);      \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                                   \
+    } while (0)
+
 
 // n / d for n < 2^31 by multiply-high (Granlund-Montgomery round-up form): 2 VALU ops instead of a ~40-instruction sequence
 struct FastDiv {

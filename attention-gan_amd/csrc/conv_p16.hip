@@ -410,7 +410,7 @@ void launch_ni(const void* in, const void* wk, const float* bias, void* dst, con
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         (void)attr_;                                                                                                                     \
-        hipLaunchKernelGGL((conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask); \
+        AGAN_LAUNCH((conv_p16_kernel<ET, GK, BN, IN16, OUT16, NI_>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask); \
     } while (0)
     if (p.NI == 1) AGAN_P16_LAUNCH(1);
     else AGAN_P16_LAUNCH(2);
@@ -426,7 +426,7 @@ void launch_px2(const void* in, const void* wk, const float* bias, void* dst, co
     static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr_;
-    hipLaunchKernelGGL((conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask);
+    AGAN_LAUNCH((conv_p16_kernel<ET, 1, BN, IN16, OUT16, 1, true>), grid, dim3(256), smem, st, in, w, bias, dst, g, p, act, mask);
 }
 template <int ET, int GK, int BN>
 void launch_dt(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int act, const void* mask,

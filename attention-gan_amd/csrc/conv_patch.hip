@@ -1063,11 +1063,11 @@ void launch_nt(const float* in, const void* wk, const float* bias, float* dst, c
     if (pp.NT == 9) {
         static const hipError_t a9 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a9;
-        hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
+        AGAN_LAUNCH((conv_patch_kernel2<ET, NPL, BN, 9>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
     } else {
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel2<ET, NPL, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
-        hipLaunchKernelGGL((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
+        AGAN_LAUNCH((conv_patch_kernel2<ET, NPL, BN, 4>), grid, dim3(256), smem, st, in, w, bias, dst, g, pp, p.ksplit, p.stages_per_split, p.slab, act, mask, plane, in_scale, out_amax);
     }
 }
 template <int ET, int NPL>
@@ -1083,9 +1083,9 @@ void launch_wg_nt(const void* x, const void* dy, float* part, const Geom& g, con
                   const float* xs = nullptr, const float* ys = nullptr) {
     dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
     if (pp.NT == 9)
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 9, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
+        AGAN_LAUNCH((conv_patch_wgrad_kernel<ET, NPL, BJ, 9, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
     else
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, NPL, BJ, 4, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
+        AGAN_LAUNCH((conv_patch_wgrad_kernel<ET, NPL, BJ, 4, X16, Y16>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, xs, ys);
 }
 // one-plane modes with typed activation storage
 // can the row-block staging take this weight gradient?  (8-pixel chunks inside tile rows, whole 16-byte blocks per tensor row, one x
@@ -1102,9 +1102,9 @@ template <int ET, int BJ>
 void launch_wg_b16(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st) {
     dim3 grid(p.jtiles, pp.nstages, p.ncls * p.psplit);
     if (pp.NT == 9)
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, 1, BJ, 9, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
+        AGAN_LAUNCH((conv_patch_wgrad_kernel<ET, 1, BJ, 9, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((conv_patch_wgrad_kernel<ET, 1, BJ, 4, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
+        AGAN_LAUNCH((conv_patch_wgrad_kernel<ET, 1, BJ, 4, true, true, true>), grid, dim3(256), 0, st, x, dy, part, g, pp, p.psplit, p.tiles_per_split, p.slab, (const float*)nullptr, (const float*)nullptr);
 }
 template <int ET, int BJ>
 void launch_wg_dt(const void* x, const void* dy, float* part, const Geom& g, const PatchPlan& pp, const PatchWgrad& p, hipStream_t st, bool x16,
@@ -1142,7 +1142,7 @@ extern "C" int agan_absmax(const float* x, size_t n, float* amax_slot, void* str
     AGAN_REQUIRE(x && amax_slot && n > 0, "absmax: bad argument");
     AGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: tensor must be 16-byte aligned");
     const unsigned blocks = (unsigned)std::min<size_t>(cdivz(n / 4 + 1, 256 * 8), 1024);
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, amax_slot);
+    AGAN_LAUNCH(absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, amax_slot);
     return check_launch("absmax");
 }
 
@@ -1267,7 +1267,7 @@ int pack_weight_patch(const float* w, void* wk, int mode, int cout, int cin, int
     const FastDiv drow = make_fastdiv((unsigned)((pack_n_is_cout(mode) ? kCH : kPackN) * kh * kw));
     PackPlanLite pl;
     pl.IS = pp.IS; pl.NPH = pp.NPH; pl.NT = pp.NT; pl.nsteps = pp.nsteps;
-#define AGAN_PK(ET, NPL) hipLaunchKernelGGL((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pl, drow, dkk)
+#define AGAN_PK(ET, NPL) AGAN_LAUNCH((pack_patch_weight_kernel<ET, NPL>), blocks, dim3(256), 0, st, w, o, mode, cout, cin, kh, kw, ncls, K, R, S, Nld, pl, drow, dkk)
     switch (prec) {
         case AGAN_PREC_BF16: AGAN_PK(0, 1); break;
         case AGAN_PREC_F16: AGAN_PK(1, 1); break;
@@ -1289,7 +1289,7 @@ int pack_job_blocks_patch(int mode, int cout, int cin, int kh, int kw) {
 }
 
 int pack_weights_patch(const agan_pack_job* jobs, int njobs, int total_blocks, int prec, hipStream_t st) {
-#define AGAN_PKJ(ET, NPL) hipLaunchKernelGGL((pack_patch_jobs_kernel<ET, NPL>), dim3(total_blocks), dim3(256), 0, st, jobs, njobs)
+#define AGAN_PKJ(ET, NPL) AGAN_LAUNCH((pack_patch_jobs_kernel<ET, NPL>), dim3(total_blocks), dim3(256), 0, st, jobs, njobs)
     switch (prec) {
         case AGAN_PREC_BF16: AGAN_PKJ(0, 1); break;
         case AGAN_PREC_F16: AGAN_PKJ(1, 1); break;
@@ -1339,13 +1339,13 @@ void launch_patch_wgrad(const void* x, const void* dy, float* part, const Geom& 
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, int NPH, int NT, int Kp, int accumulate,
                                hipStream_t st) {
     const size_t total = (size_t)cout * cin * kh * kw;
-    hipLaunchKernelGGL(unpack_patch_wgrad_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st, red, dw, cout, cin,
+    AGAN_LAUNCH(unpack_patch_wgrad_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, st, red, dw, cout, cin,
                        kh, kw, up ? 1 : 0, NPH, NT, Kp, accumulate);
 }
 void launch_wgrad_sum_unpack(const float* slabs, int nslabs, size_t slab, float* dw, int cout, int cin, int kh, int kw, int NPH, int NT, int Kp,
                              int accumulate, hipStream_t st) {
     const int ntiles = cout * cdiv(cin, kCH);
-    hipLaunchKernelGGL(sum_unpack_wgrad_kernel, dim3((unsigned)std::min(cdiv(ntiles, 4), 8192)), dim3(256), 0, st, slabs, nslabs, slab, dw, cout, cin, kh,
+    AGAN_LAUNCH(sum_unpack_wgrad_kernel, dim3((unsigned)std::min(cdiv(ntiles, 4), 8192)), dim3(256), 0, st, slabs, nslabs, slab, dw, cout, cin, kh,
                        kw, NPH, NT, Kp, accumulate);
 }
 void launch_patch_wgrad_unpack(const float* red, float* dw, int cout, int cin, int kh, int kw, bool up, const PatchPlan& pp, const PatchWgrad& p,

@@ -319,22 +319,22 @@ bool small_n_gather_supported(const Geom& g) {
 
 void launch_gather_small_n(const void* in, const float* wk, const float* bias, float* out, const Geom& g, hipStream_t st, int in_dtype) {
     if (g.RS == 1 && g.IH == 1 && g.IW == 1 && g.OS == 1 && g.SY == 1 && g.OY0 == 0) {       // a linear layer: one row per workgroup (fp32 only)
-        hipLaunchKernelGGL(linear_small_n_kernel, dim3(g.Mtot), dim3(256), 0, st, static_cast<const float*>(in), wk, bias, out, g.K, g.Nld, g.Cout);
+        AGAN_LAUNCH(linear_small_n_kernel, dim3(g.Mtot), dim3(256), 0, st, static_cast<const float*>(in), wk, bias, out, g.K, g.Nld, g.Cout);
         return;
     }
     if (strip_ok(g)) {
         const dim3 sg(cdiv(g.B * g.IH * (g.IW >> 2), 256));
-        if (in_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((conv_small_strip_kernel<AGAN_DT_BF16>), sg, dim3(256), 0, st, in, wk, bias, out, g);
-        else if (in_dtype == AGAN_DT_F16) hipLaunchKernelGGL((conv_small_strip_kernel<AGAN_DT_F16>), sg, dim3(256), 0, st, in, wk, bias, out, g);
-        else hipLaunchKernelGGL((conv_small_strip_kernel<AGAN_DT_F32>), sg, dim3(256), 0, st, in, wk, bias, out, g);
+        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_BF16>), sg, dim3(256), 0, st, in, wk, bias, out, g);
+        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F16>), sg, dim3(256), 0, st, in, wk, bias, out, g);
+        else AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F32>), sg, dim3(256), 0, st, in, wk, bias, out, g);
         return;
     }
     dim3 grid(cdiv(g.Mtot, 256), g.OS * g.OS);
 #define AGAN_SN(RS_, S_)                                                                                                                  \
     do {                                                                                                                                  \
-        if (in_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_, AGAN_DT_BF16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
-        else if (in_dtype == AGAN_DT_F16) hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_, AGAN_DT_F16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
-        else hipLaunchKernelGGL((conv_small_n_kernel<RS_, S_>), grid, dim3(256), 0, st, in, wk, bias, out, g);                              \
+        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_n_kernel<RS_, S_, AGAN_DT_BF16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
+        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_n_kernel<RS_, S_, AGAN_DT_F16>), grid, dim3(256), 0, st, in, wk, bias, out, g); \
+        else AGAN_LAUNCH((conv_small_n_kernel<RS_, S_>), grid, dim3(256), 0, st, in, wk, bias, out, g);                              \
     } while (0)
     switch (g.RS) {
         case 1: AGAN_SN(1, 1); break;
@@ -360,14 +360,14 @@ SmallWgradPlan plan_wgrad_small_n(const Geom& g) {
 void launch_wgrad_small_n(const void* x, const float* dy, float* part, const Geom& g, const SmallWgradPlan& p, hipStream_t st, int x_dtype) {
     if (strip_ok(g) && (p.pchunk & 3) == 0) {       // the plan's pixel chunks are whole strips (multiples of 256 pixels)
         const dim3 sg(g.Cin, p.nchunk);
-        if (x_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((wgrad_small_strip_kernel<AGAN_DT_BF16>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
-        else if (x_dtype == AGAN_DT_F16) hipLaunchKernelGGL((wgrad_small_strip_kernel<AGAN_DT_F16>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
-        else hipLaunchKernelGGL((wgrad_small_strip_kernel<AGAN_DT_F32>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
+        if (x_dtype == AGAN_DT_BF16) AGAN_LAUNCH((wgrad_small_strip_kernel<AGAN_DT_BF16>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
+        else if (x_dtype == AGAN_DT_F16) AGAN_LAUNCH((wgrad_small_strip_kernel<AGAN_DT_F16>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
+        else AGAN_LAUNCH((wgrad_small_strip_kernel<AGAN_DT_F32>), sg, dim3(256), 0, st, x, dy, part, g, p.pchunk >> 2, p.slab);
         return;
     }
-    if (x_dtype == AGAN_DT_BF16) hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3, AGAN_DT_BF16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
-    else if (x_dtype == AGAN_DT_F16) hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3, AGAN_DT_F16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
-    else hipLaunchKernelGGL((wgrad_small_n_kernel<9, 3>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+    if (x_dtype == AGAN_DT_BF16) AGAN_LAUNCH((wgrad_small_n_kernel<9, 3, AGAN_DT_BF16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+    else if (x_dtype == AGAN_DT_F16) AGAN_LAUNCH((wgrad_small_n_kernel<9, 3, AGAN_DT_F16>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
+    else AGAN_LAUNCH((wgrad_small_n_kernel<9, 3>), dim3(g.Cin, p.nchunk), dim3(256), 0, st, x, dy, part, g, p.pchunk, p.slab);
 }
 
 }  // namespace conv

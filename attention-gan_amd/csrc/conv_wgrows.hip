@@ -420,7 +420,7 @@ void launch_rows(const void* x, const void* dy, float* part, const Geom& g, cons
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
         (void)attr_;                                                                                                                                  \
-        hipLaunchKernelGGL((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
+        AGAN_LAUNCH((conv_wgrad_rows_kernel<ET, NPL, GK, CI2, X16, Y16, NIX, NIY, PC_, UPS>), grid, dim3(PC_ ? 512 : 256), (size_t)p.smem_bytes, st, x, dy, \
                            part, g, p, xs, ys);                                                                                                       \
     } while (0)
     if constexpr (NPL == 1 && ET != 2) {

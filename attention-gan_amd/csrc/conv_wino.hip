@@ -1131,43 +1131,43 @@ void launch_wino(const float* in, const float* wk, float* out, const Geom& g, co
     const int total = g.Cin * g.Nld;
     dim3 grid(p.mtiles * p.ntiles * p.ksplit);
     if (p.s2 == 2) {
-        hipLaunchKernelGGL(wino_cls_weight_transform_kernel, dim3(std::min(cdiv(4 * total, 256), 4096)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+        AGAN_LAUNCH(wino_cls_weight_transform_kernel, dim3(std::min(cdiv(4 * total, 256), 4096)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
         dim3 gridc(p.mtiles * p.ntiles * 4);
         if (p.nf == 4) {
             static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cls_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)a4;
-            hipLaunchKernelGGL(conv_wino_cls_f32_kernel<4>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+            AGAN_LAUNCH(conv_wino_cls_f32_kernel<4>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
         } else {
             static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cls_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)a2;
-            hipLaunchKernelGGL(conv_wino_cls_f32_kernel<2>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+            AGAN_LAUNCH(conv_wino_cls_f32_kernel<2>, gridc, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
         }
         return;
     }
     if (p.s2) {
-        hipLaunchKernelGGL(wino_s2_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+        AGAN_LAUNCH(wino_s2_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_s2_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
         // (a split launch writes its partial sums to the slabs behind U in the workspace: the caller sums them into `out`)
         float* dst = p.ksplit > 1 ? reinterpret_cast<float*>(static_cast<char*>(ws) + p.u_bytes) : out;
-        hipLaunchKernelGGL(conv_wino_s2_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, dst, g, p);
+        AGAN_LAUNCH(conv_wino_s2_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, dst, g, p);
         return;
     }
-    hipLaunchKernelGGL(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
+    AGAN_LAUNCH(wino_weight_transform_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, st, wk, U, g.Cin, g.Nld, g.Cout);
     if (p.hmode) {
         static const hipError_t ah = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)ah;
-        hipLaunchKernelGGL(conv_wino_h_f32_kernel, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        AGAN_LAUNCH(conv_wino_h_f32_kernel, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
         return;
     }
     if (p.nf == 4) {
         static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a4;
-        hipLaunchKernelGGL(conv_wino_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        AGAN_LAUNCH(conv_wino_f32_kernel<4>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
     } else {
         static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)a2;
-        hipLaunchKernelGGL(conv_wino_f32_kernel<2>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
+        AGAN_LAUNCH(conv_wino_f32_kernel<2>, grid, dim3(256), (size_t)p.smem_bytes, st, in, U, out, g, p);
     }
 }
 
@@ -1198,12 +1198,12 @@ WinoWgradPlan plan_wino_wgrad(const Geom& g) {
 void launch_wino_wgrad(const float* x, const float* dy, float* part, const Geom& g, const WinoWgradPlan& p, hipStream_t st) {
     static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)a;
-    hipLaunchKernelGGL(conv_wino_wgrad_f32_kernel, dim3(p.jtiles * p.itiles * p.psplit), dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p);
+    AGAN_LAUNCH(conv_wino_wgrad_f32_kernel, dim3(p.jtiles * p.itiles * p.psplit), dim3(256), (size_t)p.smem_bytes, st, x, dy, part, g, p);
 }
 
 void launch_wino_wgrad_sum(const float* part, const Geom& g, const WinoWgradPlan& p, float* dw, int accumulate, hipStream_t st) {
     const int n4 = 9 * g.Cout * (g.Cin >> 2);
-    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(std::min(cdiv(n4, 32), 8192)), dim3(256), 0, st, part, p.psplit, p.slab, g.Cout, g.Cin, dw, accumulate);
+    AGAN_LAUNCH(wino_wgrad_sum_kernel, dim3(std::min(cdiv(n4, 32), 8192)), dim3(256), 0, st, part, p.psplit, p.slab, g.Cout, g.Cin, dw, accumulate);
 }
 
 }  // namespace conv

@@ -35,3 +35,22 @@ class Generator(nn.Module):
             fake_imgs.append(head(images))
             attn_maps.append(attn)
         return (fake_imgs, attn_maps, mu, logvar)
+
+
+class Generator1(nn.Module):
+    """Stage-1 only (BASELINE.json configs[1]: 64x64 G + D): the CA-net, the initial stage and its image head of the generator
+    above (generator.py:26-30 of the reference), nothing of stages 2 / 3 -- same submodule names, so a full Generator's
+    `vae.*`, `gen1.*`, `img_out1.*` entries load into it.  forward() keeps the Generator's signature and return shape
+    (one image, no attention maps), so trainers.GanTrainStep drives it with a single discriminator."""
+
+    def __init__(self, gf_dim: int, emb_dim: int, z_dim: int, cond_dim: int):
+        super().__init__()
+        self.gf_dim, self.emb_dim, self.z_dim, self.cond_dim = gf_dim, emb_dim, z_dim, cond_dim
+        self.vae = VarAutoEncoder(emb_dim=emb_dim, cond_dim=cond_dim)
+        self.gen1 = GenInitialStage(gf_dim=gf_dim * 16, z_dim=z_dim, cond_dim=cond_dim)
+        self.img_out1 = GenMakeImage(gf_dim=gf_dim)
+
+    def forward(self, noise: Tensor, sent_emb: Tensor, word_embs: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+                eps: Optional[Tensor] = None):
+        condition, mu, logvar = self.vae(sent_emb, eps)
+        return ([self.img_out1(self.gen1(noise, condition))], [], mu, logvar)

@@ -323,6 +323,10 @@ int agan_timer_create(void** event);
 int agan_timer_destroy(void* event);
 int agan_timer_arm(void* start, void* stop);
 int agan_timer_elapsed_ms(void* start, void* stop, float* ms);
+/* The kernel the most recent TIMED call on this thread ran as its main kernel: the demangled symbol exactly as `rocprofv3
+ * --kernel-trace --stats` names it (e.g. "void (anonymous namespace)::conv_gather_f32_kernel<128, 128, 2, 2, 0>(float const*, ...)"),
+ * copied into name[capacity]; empty if nothing has been timed.  bench.py keys `roofline_by_kernel` with it. */
+int agan_timer_last_kernel(char* name, size_t capacity);
 
 static inline int agan_round_up(int v, int m) { return (v + m - 1) / m * m; }
 

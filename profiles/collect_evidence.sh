@@ -1,15 +1,17 @@
 #!/bin/bash
-# usage: bash profiles/collect_evidence.sh MODE [STORAGE] [TAG]   (on the GPU box, from the repo root)
-#   MODE = --precision of bench.py, STORAGE = --storage (default f32), TAG = file prefix (default r03_${MODE}[_s16])
-#   writes gpurun_out/${TAG}_*: copy those into profiles/
+# usage: bash profiles/collect_evidence.sh MODE [STORAGE] [TAG] [WORKLOAD]   (on the GPU box, from the repo root)
+#   MODE = --precision of bench.py, STORAGE = --storage (default f32), WORKLOAD = --workload (default full3),
+#   TAG = file prefix (default r04_${MODE}[_s16][_${WORKLOAD}]); writes gpurun_out/${TAG}_*: copy those into profiles/
 MODE=$1
 STORAGE=${2:-f32}
-if [ "$STORAGE" = "f32" ]; then DEF=r03_${MODE}; else DEF=r03_${MODE}_s16; fi
+WORKLOAD=${4:-full3}
+if [ "$STORAGE" = "f32" ]; then DEF=r04_${MODE}; else DEF=r04_${MODE}_s16; fi
+if [ "$WORKLOAD" != "full3" ]; then DEF=${DEF}_${WORKLOAD}; fi
 TAG=${3:-$DEF}
 R=$GRAFT_REPO_ROOT
 case $MODE in f16*) LOWC=SQ_INSTS_VALU_MFMA_MOPS_F16;; *) LOWC=SQ_INSTS_VALU_MFMA_MOPS_BF16;; esac
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --precision $MODE --storage $STORAGE"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --graph off --workload $WORKLOAD --precision $MODE --storage $STORAGE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_${TAG}_stats -o p -- $B > /dev/null 2>&1 &&
 # (the counter passes run the three discriminator updates on ONE stream: a kernel's counters are per dispatch, and kernels of different
 #  streams sharing the chip dilute each other's busy fractions; the kernel-time shares come from the pass above, which overlaps them)

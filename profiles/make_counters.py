@@ -90,6 +90,21 @@ def bench_name(kernel, mode):
     return None
 
 
+def short_symbol(name):
+    """same rule as bench.py::short_symbol: the kernel symbol without return type, anonymous namespace and parameter list"""
+    s = name[5:] if name.startswith("void ") else name
+    s = s.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(s):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return s[:i]
+    return s
+
+
 def read_pass(directory):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -106,7 +121,7 @@ def read_pass(directory):
 
 def main():
     prefix, out_dir, tag = sys.argv[1:4]
-    parts = tag.split("_")                       # r03_bf16 / r03_bf16_s16 (16-bit activation storage)
+    parts = [p for p in tag.split("_") if p not in ("stage1", "b64", "stage4", "b8")]      # r04_bf16 / r04_bf16_s16 / r04_bf16_stage1_b64
     mode = parts[-2] if parts[-1] == "s16" else parts[-1]
     mfma, fetch, write = read_pass(prefix + "_mfma"), read_pass(prefix + "_fetch"), read_pass(prefix + "_write")
     stats = glob.glob(os.path.join(prefix + "_stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -187,6 +202,23 @@ def main():
             for (inst, grid), L in sorted(layers.items(), key=lambda kv: -kv[1]["ns"]):
                 w.writerow([inst, grid, L["n"], round(L["ns"] / L["n"] / 1e3, 1), round(L["ns"] / 1e6, 3),
                             round(100.0 * L["busy"] / (L["gui"] * 128.0), 1) if L["gui"] else ""])
+    # per kernel SYMBOL (round 4): what bench.py's roofline / roofline_by_kernel look up -- keyed like rocprofv3's kernel_stats.csv
+    sym = {}
+    for d in mfma.values():
+        e = sym.setdefault(short_symbol(d["kernel"]), {"n": 0, "ns": 0, "busy": 0.0, "gui": 0.0, "fetch": 0.0, "write": 0.0, "nf": 0, "nw": 0})
+        e["n"] += 1
+        e["ns"] += d["t1"] - d["t0"]
+        e["busy"] += d["c"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        e["gui"] += d["c"].get("GRBM_GUI_ACTIVE", 0.0)
+    for src, key, cnt, cname in ((fetch, "fetch", "nf", "FETCH_SIZE"), (write, "write", "nw", "WRITE_SIZE")):
+        for d in src.values():
+            e = sym.setdefault(short_symbol(d["kernel"]), {"n": 0, "ns": 0, "busy": 0.0, "gui": 0.0, "fetch": 0.0, "write": 0.0, "nf": 0, "nw": 0})
+            e[key] += d["c"].get(cname, 0.0) * 1024
+            e[cnt] += 1
+    symbols = {k: {"launches": e["n"], "avg_ms": round(e["ns"] / max(1, e["n"]) / 1e6, 4),
+                   "mfma_busy_pct": round(100.0 * e["busy"] / (e["gui"] * 128.0), 1) if e["gui"] else None,
+                   "traffic": round(2 * e["fetch"] / max(1, e["nf"]) + e["write"] / max(1, e["nw"])) if (e["nf"] or e["nw"]) else None}
+               for k, e in sorted(sym.items(), key=lambda kv: -kv[1]["ns"]) if e["ns"] >= 0.002 * max(1, total_ns)}
     kernels = {b: {"launches": max(c["nf"], c["nw"]), "fetch_size_raw": round(c["fetch"] / max(1, c["nf"])),
                    "write_size": round(c["write"] / max(1, c["nw"])),
                    "traffic": round(2 * c["fetch"] / max(1, c["nf"]) + c["write"] / max(1, c["nw"]))} for b, c in sorted(conv.items())}
@@ -196,7 +228,11 @@ def main():
            "unit": "bytes per launch (average over all launches of the kernel in the run)",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH_SIZE + WRITE_SIZE; "
                          "the x2 is calibrated for 16-B/lane streams, so it is an upper bound for the 4-B/lane patch loads",
-           "kernels": kernels}
+           "kernels": kernels,
+           "symbols_note": "per kernel symbol (as rocprofv3 names it, without return type / namespace / parameters): launches and average "
+                           "duration in the MFMA pass (--single-stream), MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128), "
+                           "traffic = 2*FETCH_SIZE + WRITE_SIZE bytes per launch; kernels below 0.2 % of the kernel time omitted",
+           "symbols": symbols}
     with open(os.path.join(out_dir, f"{tag}_traffic.json"), "w") as fh:
         json.dump(doc, fh, indent=1)
     for r in rows:
