@@ -303,6 +303,7 @@ struct P16Plan {
     int buf_bytes, smem_bytes;          // one LDS patch buffer (the kernel holds two); dynamic LDS of the launch
     int lds_epi;                        // 16-bit output leaves through LDS as 16-byte stores
     int px2;                            // GK 1 on a stride-2 lattice: both column-parity classes in one workgroup (grid classes = row parities)
+    int wc, lp;                         // cout fragments per wave (1, or 2: the 64 x 128 register tile); log2 of the lattice points per workgroup tile
     size_t slab, ws_bytes;
     FastDiv dNXB, dPH, dTB;
 };
