@@ -19,7 +19,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf
 struct Chunk { int beg, end; };
 
 __device__ __forceinline__ Chunk chunk_of(int n, int nchunk, int chunk) {
-    int len = (cdiv(n, nchunk) + 3) & ~3;
+    int len = (cdiv(n, nchunk) + 7) & ~7;          // (whole 8-element groups: the widest vector access of the kernels below)
     Chunk c;
     c.beg = min(n, chunk * len);
     c.end = min(n, c.beg + len);
@@ -38,7 +38,19 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __res
     const int n = B * HW;
     const Chunk ch = chunk_of(n, nchunk, chunk);
     double s = 0.0, q = 0.0;
-    if ((HW & 3) == 0) {
+    if (XDT != AGAN_DT_F32 && (HW & 7) == 0) {           // 16-bit storage: 8 values = one 16-byte load (chunks are multiples of 8 then)
+        for (int i = ch.beg + threadIdx.x * 8; i < ch.end; i += 2048) {
+            const int b = i / HW, p = i - b * HW;
+            float v[8];
+            ldv<XDT, 8>(x, ((size_t)b * C + c) * HW + p, v);
+            float s4 = 0.f;                              // (8 values of one bf16 / fp16 tensor: the fp32 partial is exact enough, the chain stays fp64)
+            double q4 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s4 += v[k]; q4 += (double)v[k] * v[k]; }
+            s += (double)s4;
+            q += q4;
+        }
+    } else if ((HW & 3) == 0) {
         for (int i = ch.beg + threadIdx.x * 4; i < ch.end; i += 1024) {
             const int b = i / HW, p = i - b * HW;
             const float4 v = ld4<XDT>(x, ((size_t)b * C + c) * HW + p);
@@ -133,12 +145,12 @@ __device__ __forceinline__ Affine affine_of(const float* mean, const float* invs
 }
 
 // XDT: storage type of x; ODT: of out and the residual
-template <int ACT, bool VEC, int XDT, int ODT>
+// V: elements per thread and iteration (1, 4, or 8 where a 16-bit tensor is involved: 16-byte accesses on it)
+template <int ACT, int V, int XDT, int ODT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const void* __restrict__ res,
                                                          void* __restrict__ out, int B, int C, int HW, float* __restrict__ amax) {
-    constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
     const size_t total = (size_t)B * Co * HW / V;
     float mx = 0.f;
@@ -149,15 +161,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
         const int c = (int)(t % Co), b = (int)(t / Co);
         const size_t xi = ((size_t)b * C + c) * HW + p;
         const Affine a = affine_of(mean, invstd, gamma, beta, c);
-        float xv[4], yv[4];
-        if (VEC) *reinterpret_cast<float4*>(xv) = ld4<XDT>(x, xi);
-        else xv[0] = ld1<XDT>(x, xi);
+        float xv[V], yv[V];
+        ldv<XDT, V>(x, xi, xv);
         if (ACT == AGAN_ACT_GLU) {
             const Affine g = affine_of(mean, invstd, gamma, beta, c + Co);
-            float gv[4];
-            const size_t gi = xi + (size_t)Co * HW;
-            if (VEC) *reinterpret_cast<float4*>(gv) = ld4<XDT>(x, gi);
-            else gv[0] = ld1<XDT>(x, gi);
+            float gv[V];
+            ldv<XDT, V>(x, xi + (size_t)Co * HW, gv);
 #pragma unroll
             for (int k = 0; k < V; ++k) yv[k] = (xv[k] * a.s + a.t) * sigmoidf_(gv[k] * g.s + g.t);
         } else {
@@ -168,17 +177,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
                 yv[k] = z;
             }
             if (res) {
-                float rv[4];
-                if (VEC) *reinterpret_cast<float4*>(rv) = ld4<ODT>(res, i);
-                else rv[0] = ld1<ODT>(res, i);
+                float rv[V];
+                ldv<ODT, V>(res, i, rv);
 #pragma unroll
                 for (int k = 0; k < V; ++k) yv[k] += rv[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) mx = fmaxf(mx, fabsf(yv[k]));
-        if (VEC) st4<ODT>(out, i, *reinterpret_cast<float4*>(yv));
-        else st1<ODT>(out, i, yv[0]);
+        stv<ODT, V>(out, i, yv);
     }
     if (amax) amax_commit(mx, amax);
 }
@@ -220,13 +227,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restr
     const float ma = mean[c], ia = invstd[c];
     const float mg = (ACT == AGAN_ACT_GLU) ? mean[c + Co] : 0.f, ig = (ACT == AGAN_ACT_GLU) ? invstd[c + Co] : 0.f;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    const bool vec = (HW & 3) == 0;
-    const int step = vec ? 4 : 1;
+    constexpr bool any16 = XDT != AGAN_DT_F32 || ODT != AGAN_DT_F32;
+    const bool vec = (HW & 3) == 0, vec8 = any16 && (HW & 7) == 0;      // (a 16-bit tensor involved: 8 values = 16 bytes of it)
+    const int step = vec8 ? 8 : (vec ? 4 : 1);
     for (int i = ch.beg + threadIdx.x * step; i < ch.end; i += 256 * step) {
         const int b = i / HW, p = i - b * HW;
         const size_t xi = ((size_t)b * C + c) * HW + p, di = ((size_t)b * Co + c) * HW + p;
-        float xa[4], xg[4] = {0, 0, 0, 0}, d[4];
-        if (vec) {
+        float xa[8], xg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d[8];
+        if (vec8) {
+            ldv<XDT, 8>(x, xi, xa);
+            ldv<ODT, 8>(dout, di, d);
+            if (ACT == AGAN_ACT_GLU) ldv<XDT, 8>(x, xi + (size_t)Co * HW, xg);
+        } else if (vec) {
             *reinterpret_cast<float4*>(xa) = ld4<XDT>(x, xi);
             *reinterpret_cast<float4*>(d) = ld4<ODT>(dout, di);
             if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = ld4<XDT>(x, xi + (size_t)Co * HW);
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restr
             if (ACT == AGAN_ACT_GLU) xg[0] = ld1<XDT>(x, xi + (size_t)Co * HW);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             if (k >= step) break;
             float dza, dzg;
             dz_of<ACT>(xa[k], xg[k], d[k], a, g, dza, dzg);
@@ -278,13 +290,12 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
     coef[2 * c + 1] = (float)(q / n);
 }
 
-template <int ACT, bool VEC, int XDT, int ODT>
+template <int ACT, int V, int XDT, int ODT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dout,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ coef, void* __restrict__ dx, int B, int C, int HW,
                                                            float* __restrict__ amax) {
-    constexpr int V = VEC ? 4 : 1;
     const int Co = (ACT == AGAN_ACT_GLU) ? C / 2 : C;
     const size_t total = (size_t)B * Co * HW / V;
     float mx = 0.f;
@@ -297,16 +308,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         const Affine a = affine_of(mean, invstd, gamma, beta, c);
         const Affine g = (ACT == AGAN_ACT_GLU) ? affine_of(mean, invstd, gamma, beta, c + Co) : a;
         const float ma = mean[c], ia = invstd[c], c0 = coef[2 * c], c1 = coef[2 * c + 1];
-        float xa[4], xg[4] = {0, 0, 0, 0}, d[4], oa[4], og[4];
-        if (VEC) {
-            *reinterpret_cast<float4*>(xa) = ld4<XDT>(x, xi);
-            *reinterpret_cast<float4*>(d) = ld4<ODT>(dout, i);
-            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = ld4<XDT>(x, xi + (size_t)Co * HW);
-        } else {
-            xa[0] = ld1<XDT>(x, xi);
-            d[0] = ld1<ODT>(dout, i);
-            if (ACT == AGAN_ACT_GLU) xg[0] = ld1<XDT>(x, xi + (size_t)Co * HW);
-        }
+        float xa[V], xg[V], d[V], oa[V], og[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) xg[k] = 0.f;
+        ldv<XDT, V>(x, xi, xa);
+        ldv<ODT, V>(dout, i, d);
+        if (ACT == AGAN_ACT_GLU) ldv<XDT, V>(x, xi + (size_t)Co * HW, xg);
         float mg = 0, ig = 0, g0 = 0, g1 = 0;
         if (ACT == AGAN_ACT_GLU) { mg = mean[c + Co]; ig = invstd[c + Co]; g0 = coef[2 * (c + Co)]; g1 = coef[2 * (c + Co) + 1]; }
 #pragma unroll
@@ -317,13 +324,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
             mx = fmaxf(mx, fabsf(oa[k]));
             if (ACT == AGAN_ACT_GLU) { og[k] = g.s * (dzg - g0 - (xg[k] - mg) * ig * g1); mx = fmaxf(mx, fabsf(og[k])); }
         }
-        if (VEC) {
-            st4<XDT>(dx, xi, *reinterpret_cast<float4*>(oa));
-            if (ACT == AGAN_ACT_GLU) st4<XDT>(dx, xi + (size_t)Co * HW, *reinterpret_cast<float4*>(og));
-        } else {
-            st1<XDT>(dx, xi, oa[0]);
-            if (ACT == AGAN_ACT_GLU) st1<XDT>(dx, xi + (size_t)Co * HW, og[0]);
-        }
+        stv<XDT, V>(dx, xi, oa);
+        if (ACT == AGAN_ACT_GLU) stv<XDT, V>(dx, xi + (size_t)Co * HW, og);
     }
     if (amax) amax_commit(mx, amax);
 }
@@ -413,7 +415,9 @@ __device__ __forceinline__ void block_sum2_d(double& a, double& b, double (*red)
     b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 }
 
-template <int ACT, int XDT, int ODT>
+// PER = values a thread holds per half (round 4): 32 covers kSmallN; the 4x4 / 8x8 maps (n <= 512 / 2048) take PER = 2 / 8 -- the 32-deep
+// form spent most of its ~11 us on 30 dead, fully unrolled iterations (an integer division and four predicated loads each)
+template <int ACT, int XDT, int ODT, int PER = kSmallPer>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const void* __restrict__ res, void* __restrict__ out, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -424,10 +428,10 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restric
     const int Co = GLU ? C / 2 : C;
     const int c = blockIdx.x, n = B * HW;
     if (c == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-    float va[kSmallPer], vg[GLU ? kSmallPer : 1];
+    float va[PER], vg[GLU ? PER : 1];
     double s = 0.0, q = 0.0, sg = 0.0, qg = 0.0;
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int i = threadIdx.x + j * 256;
         va[j] = 0.f;
         if (GLU) vg[j] = 0.f;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restric
     float sgs = 0.f, tg = 0.f, mx = 0.f;
     if (GLU) { sgs = gamma[c + Co] * isg; tg = beta[c + Co] - mgf * sgs; }
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int i = threadIdx.x + j * 256;
         if (i < n) {
             const int b = i / HW, p = i - b * HW;
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restric
     if (amax) amax_commit(mx, amax);
 }
 
-template <int ACT, int XDT, int ODT>
+template <int ACT, int XDT, int ODT, int PER = kSmallPer>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dout, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, void* __restrict__ dx, float* __restrict__ dgamma,
@@ -510,10 +514,10 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restric
     const Affine g = GLU ? affine_of(mean, invstd, gamma, beta, c + Co) : a;
     const float ma = mean[c], ia = invstd[c];
     const float mg = GLU ? mean[c + Co] : 0.f, ig = GLU ? invstd[c + Co] : 0.f;
-    float xa[kSmallPer], za[kSmallPer], xg[GLU ? kSmallPer : 1], zg[GLU ? kSmallPer : 1];
+    float xa[PER], za[PER], xg[GLU ? PER : 1], zg[GLU ? PER : 1];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int i = threadIdx.x + j * 256;
         xa[j] = 0.f; za[j] = 0.f;
         if (GLU) { xg[j] = 0.f; zg[j] = 0.f; }
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restric
     const float c0 = (float)(s0 / n), c1 = (float)(s1 / n), g0 = (float)(s2 / n), g1 = (float)(s3 / n);
     float mx = 0.f;
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int i = threadIdx.x + j * 256;
         if (i < n) {
             const int b = i / HW, p = i - b * HW;
@@ -632,16 +636,24 @@ int agan_bn_act_fwd_dt(const void* x, const float* mean, const float* invstd, co
     AGAN_REQUIRE(!(residual && act != AGAN_ACT_NONE), "bn_act_fwd: residual only with ACT_NONE");
     AGAN_REQUIRE(bn_dt_ok(x_dtype, out_dtype), "bn_act_fwd: storage types %d -> %d", x_dtype, out_dtype);
     hipStream_t st = as_stream(stream);
-    const bool vec = (HW & 3) == 0;
+    // elements per thread and iteration: 8 where a 16-bit tensor is involved and rows are whole 8-groups (16-byte accesses on it), else 4 / 1
+    const int vw = ((x_dtype != AGAN_DT_F32 || out_dtype != AGAN_DT_F32) && (HW & 7) == 0) ? 8 : ((HW & 3) == 0 ? 4 : 1);
     const int Co = act == AGAN_ACT_GLU ? C / 2 : C;
-    const int blocks = ew_blocks((size_t)B * Co * HW / (vec ? 4 : 1));
+    const int blocks = ew_blocks((size_t)B * Co * HW / vw);
 #define AGAN_L(A, V, XD, OD) hipLaunchKernelGGL((bn_act_fwd_kernel<A, V, XD, OD>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, out, B, C, HW, out_amax)
-#define AGAN_C(XD, OD)                                                                                               \
-    if (act == AGAN_ACT_GLU) { if (vec) AGAN_L(AGAN_ACT_GLU, true, XD, OD); else AGAN_L(AGAN_ACT_GLU, false, XD, OD); }   \
-    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true, XD, OD); else AGAN_L(AGAN_ACT_LRELU, false, XD, OD); } \
-    else { if (vec) AGAN_L(AGAN_ACT_NONE, true, XD, OD); else AGAN_L(AGAN_ACT_NONE, false, XD, OD); }
+#define AGAN_V(A, XD, OD)                                                                                           \
+    do {                                                                                                            \
+        if (vw == 8) { if constexpr ((XD) != AGAN_DT_F32 || (OD) != AGAN_DT_F32) AGAN_L(A, 8, XD, OD); }             \
+        else if (vw == 4) AGAN_L(A, 4, XD, OD);                                                                     \
+        else AGAN_L(A, 1, XD, OD);                                                                                  \
+    } while (0)
+#define AGAN_C(XD, OD)                                                  \
+    if (act == AGAN_ACT_GLU) AGAN_V(AGAN_ACT_GLU, XD, OD);              \
+    else if (act == AGAN_ACT_LRELU) AGAN_V(AGAN_ACT_LRELU, XD, OD);     \
+    else AGAN_V(AGAN_ACT_NONE, XD, OD);
     AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
 #undef AGAN_C
+#undef AGAN_V
 #undef AGAN_L
     return check_launch("bn_act_fwd");
 }
@@ -678,7 +690,8 @@ int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const
             const void* dg = off(dout, (size_t)gi * Bg * Co * HW, out_dtype);
             void* dxg = off(dx, (size_t)gi * Bg * C * HW, x_dtype);
             const int acc = gi == 0 ? accumulate : 1;
-#define AGAN_L(A, XD, OD) hipLaunchKernelGGL((bn_small_bwd_kernel<A, XD, OD>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc, dx_amax)
+#define AGAN_LP(A, XD, OD, P) hipLaunchKernelGGL((bn_small_bwd_kernel<A, XD, OD, P>), dim3(Co), dim3(256), 0, st, xg, dg, mean + (size_t)gi * C, invstd + (size_t)gi * C, gamma, beta, dxg, dgamma, dbeta, Bg, C, HW, acc, dx_amax)
+#define AGAN_L(A, XD, OD) do { if (Bg * HW <= 512) AGAN_LP(A, XD, OD, 2); else if (Bg * HW <= 2048) AGAN_LP(A, XD, OD, 8); else AGAN_LP(A, XD, OD, kSmallPer); } while (0)
 #define AGAN_C(XD, OD)                                           \
     if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU, XD, OD);       \
     else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU, XD, OD); \
@@ -686,6 +699,7 @@ int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const
             AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
 #undef AGAN_C
 #undef AGAN_L
+#undef AGAN_LP
         }
         return check_launch("bn_act_bwd/small");
     }
@@ -693,8 +707,8 @@ int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const
     double* part = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(part + (size_t)C * nchunk * 4);
     dim3 grid(Co, nchunk);
-    const bool vec = (HW & 3) == 0;
-    const int blocks = ew_blocks((size_t)Bg * Co * HW / (vec ? 4 : 1));
+    const int vw = ((x_dtype != AGAN_DT_F32 || out_dtype != AGAN_DT_F32) && (HW & 7) == 0) ? 8 : ((HW & 3) == 0 ? 4 : 1);
+    const int blocks = ew_blocks((size_t)Bg * Co * HW / vw);
     for (int gi = 0; gi < groups; ++gi) {      // group 0 writes (or adds to) the gamma/beta gradients, the others add
         const void* xg = off(x, (size_t)gi * Bg * C * HW, x_dtype);
         const void* dg = off(dout, (size_t)gi * Bg * Co * HW, out_dtype);
@@ -712,12 +726,19 @@ int agan_bn_act_bwd_dt(const void* x, const void* dout, const float* mean, const
 #undef AGAN_P
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, Co, nchunk, Bg * HW, glu, dgamma, dbeta, coef, acc);
 #define AGAN_L(A, V, XD, OD) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, V, XD, OD>), dim3(blocks), dim3(256), 0, st, xg, dg, mg, ig, gamma, beta, coef, dxg, Bg, C, HW, dx_amax)
-#define AGAN_C(XD, OD)                                                                                               \
-    if (glu) { if (vec) AGAN_L(AGAN_ACT_GLU, true, XD, OD); else AGAN_L(AGAN_ACT_GLU, false, XD, OD); }               \
-    else if (act == AGAN_ACT_LRELU) { if (vec) AGAN_L(AGAN_ACT_LRELU, true, XD, OD); else AGAN_L(AGAN_ACT_LRELU, false, XD, OD); } \
-    else { if (vec) AGAN_L(AGAN_ACT_NONE, true, XD, OD); else AGAN_L(AGAN_ACT_NONE, false, XD, OD); }
+#define AGAN_V(A, XD, OD)                                                                                           \
+    do {                                                                                                            \
+        if (vw == 8) { if constexpr ((XD) != AGAN_DT_F32 || (OD) != AGAN_DT_F32) AGAN_L(A, 8, XD, OD); }             \
+        else if (vw == 4) AGAN_L(A, 4, XD, OD);                                                                     \
+        else AGAN_L(A, 1, XD, OD);                                                                                  \
+    } while (0)
+#define AGAN_C(XD, OD)                                                  \
+    if (glu) AGAN_V(AGAN_ACT_GLU, XD, OD);                              \
+    else if (act == AGAN_ACT_LRELU) AGAN_V(AGAN_ACT_LRELU, XD, OD);     \
+    else AGAN_V(AGAN_ACT_NONE, XD, OD);
         AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
 #undef AGAN_C
+#undef AGAN_V
 #undef AGAN_L
     }
     return check_launch("bn_act_bwd");
@@ -796,7 +817,8 @@ int agan_bn_train_fwd_dt(const void* x, const float* gamma, const float* beta, c
             void* og = off(out, (size_t)gi * Bg * Co * HW, out_dtype);
             float* mg = mean + (size_t)gi * C;
             float* ig = invstd + (size_t)gi * C;
-#define AGAN_L(A, XD, OD) hipLaunchKernelGGL((bn_small_fwd_kernel<A, XD, OD>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum, out_amax)
+#define AGAN_LP(A, XD, OD, P) hipLaunchKernelGGL((bn_small_fwd_kernel<A, XD, OD, P>), dim3(Co), dim3(256), 0, st, xg, gamma, beta, rg, og, mg, ig, running_mean, running_var, nbt, Bg, C, HW, eps, momentum, out_amax)
+#define AGAN_L(A, XD, OD) do { if (Bg * HW <= 512) AGAN_LP(A, XD, OD, 2); else if (Bg * HW <= 2048) AGAN_LP(A, XD, OD, 8); else AGAN_LP(A, XD, OD, kSmallPer); } while (0)
 #define AGAN_C(XD, OD)                                           \
     if (act == AGAN_ACT_GLU) AGAN_L(AGAN_ACT_GLU, XD, OD);       \
     else if (act == AGAN_ACT_LRELU) AGAN_L(AGAN_ACT_LRELU, XD, OD); \
@@ -804,6 +826,7 @@ int agan_bn_train_fwd_dt(const void* x, const float* gamma, const float* beta, c
             AGAN_BN_DT(x_dtype, out_dtype, AGAN_C);
 #undef AGAN_C
 #undef AGAN_L
+#undef AGAN_LP
         }
         return check_launch("bn_train_fwd/small");
     }
