@@ -5,6 +5,7 @@
 #include "agan_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 using namespace agan;
 
@@ -227,39 +228,37 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restr
     const float ma = mean[c], ia = invstd[c];
     const float mg = (ACT == AGAN_ACT_GLU) ? mean[c + Co] : 0.f, ig = (ACT == AGAN_ACT_GLU) ? invstd[c + Co] : 0.f;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    constexpr bool any16 = XDT != AGAN_DT_F32 || ODT != AGAN_DT_F32;
-    const bool vec = (HW & 3) == 0, vec8 = any16 && (HW & 7) == 0;      // (a 16-bit tensor involved: 8 values = 16 bytes of it)
-    const int step = vec8 ? 8 : (vec ? 4 : 1);
-    for (int i = ch.beg + threadIdx.x * step; i < ch.end; i += 256 * step) {
-        const int b = i / HW, p = i - b * HW;
-        const size_t xi = ((size_t)b * C + c) * HW + p, di = ((size_t)b * Co + c) * HW + p;
-        float xa[8], xg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d[8];
-        if (vec8) {
-            ldv<XDT, 8>(x, xi, xa);
-            ldv<ODT, 8>(dout, di, d);
-            if (ACT == AGAN_ACT_GLU) ldv<XDT, 8>(x, xi + (size_t)Co * HW, xg);
-        } else if (vec) {
-            *reinterpret_cast<float4*>(xa) = ld4<XDT>(x, xi);
-            *reinterpret_cast<float4*>(d) = ld4<ODT>(dout, di);
-            if (ACT == AGAN_ACT_GLU) *reinterpret_cast<float4*>(xg) = ld4<XDT>(x, xi + (size_t)Co * HW);
-        } else {
-            xa[0] = ld1<XDT>(x, xi);
-            d[0] = ld1<ODT>(dout, di);
-            if (ACT == AGAN_ACT_GLU) xg[0] = ld1<XDT>(x, xi + (size_t)Co * HW);
-        }
+    // one loop per vector width (compile-time inside: no per-element width tests): 8 values where a 16-bit tensor is involved and the rows
+    // are whole 8-groups (16-byte accesses on it), else 4, else 1
+    auto sweep = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+        for (int i = ch.beg + threadIdx.x * NV; i < ch.end; i += 256 * NV) {
+            const int b = i / HW, p = i - b * HW;
+            const size_t xi = ((size_t)b * C + c) * HW + p, di = ((size_t)b * Co + c) * HW + p;
+            float xa[NV], xg[NV], d[NV];
+            ldv<XDT, NV>(x, xi, xa);
+            ldv<ODT, NV>(dout, di, d);
+            if (ACT == AGAN_ACT_GLU) ldv<XDT, NV>(x, xi + (size_t)Co * HW, xg);
+            float t0 = 0.f, t2 = 0.f;                 // (sums of <= 8 values in fp32, the running chains in fp64)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k >= step) break;
-            float dza, dzg;
-            dz_of<ACT>(xa[k], xg[k], d[k], a, g, dza, dzg);
-            s0 += dza;
-            s1 += (double)dza * ((xa[k] - ma) * ia);
-            if (ACT == AGAN_ACT_GLU) {
-                s2 += dzg;
-                s3 += (double)dzg * ((xg[k] - mg) * ig);
+            for (int k = 0; k < NV; ++k) {
+                float dza, dzg;
+                dz_of<ACT>(xa[k], ACT == AGAN_ACT_GLU ? xg[k] : 0.f, d[k], a, g, dza, dzg);
+                t0 += dza;
+                s1 += (double)dza * ((xa[k] - ma) * ia);
+                if (ACT == AGAN_ACT_GLU) {
+                    t2 += dzg;
+                    s3 += (double)dzg * ((xg[k] - mg) * ig);
+                }
             }
+            s0 += (double)t0;
+            if (ACT == AGAN_ACT_GLU) s2 += (double)t2;
         }
-    }
+    };
+    constexpr bool any16 = XDT != AGAN_DT_F32 || ODT != AGAN_DT_F32;
+    if (any16 && (HW & 7) == 0) sweep(std::integral_constant<int, 8>{});
+    else if ((HW & 3) == 0) sweep(std::integral_constant<int, 4>{});
+    else sweep(std::integral_constant<int, 1>{});
     s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
     if (ACT == AGAN_ACT_GLU) { s2 = wave_sum_d(s2); s3 = wave_sum_d(s3); }
     const int w = threadIdx.x >> 6;

@@ -379,6 +379,32 @@ def test_image_grid_helper(tmp_path):
     assert head.startswith(b"P6\n48 48\n255\n") and os.path.getsize(paths[1]) == len(b"P6\n48 48\n255\n") + 48 * 48 * 3
 
 
+def test_stage1_generator_is_a_prefix_of_the_full_one():
+    """Generator1 (BASELINE configs[1]) = the vae / gen1 / img_out1 submodules of Generator under the same names"""
+    torch.manual_seed(3)
+    full = GEN.Generator(4, 16, 8, 8)
+    g1 = GEN.Generator1(4, 16, 8, 8)
+    keys = {k for k in full.state_dict() if k.startswith(("vae.", "gen1.", "img_out1."))}
+    assert set(g1.state_dict()) == keys
+    g1.load_state_dict({k: v for k, v in full.state_dict().items() if k in keys})
+    assert (g1.z_dim, g1.cond_dim) == (8, 8)
+
+
+def test_bench_kernel_symbol_key():
+    """bench.py / profiles/make_counters.py key per-kernel numbers with the rocprofv3 symbol minus return type, namespace and parameters"""
+    sys.path.insert(0, ROOT)
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import make_counters
+    name = ("void (anonymous namespace)::conv_gather_f32_kernel<128, 128, 2, 2, 0>(float const*, float const*, float const*, void*, "
+            "HIP_vector_type<int, 2u> const*, agan::conv::Geom, int, int, unsigned long, int, void const*)")
+    for f in (bench.short_symbol, make_counters.short_symbol):
+        assert f(name) == "conv_gather_f32_kernel<128, 128, 2, 2, 0>"
+        assert f("(anonymous namespace)::conv_wino_h_f32_kernel(float const*, float const*, float*, agan::conv::Geom, agan::conv::WinoPlan)") == "conv_wino_h_f32_kernel"
+    assert set(bench.WORKLOADS) == {"full3", "stage1_b64", "stage4_b8"}
+    assert [bench.WORKLOADS[k]["config"] for k in ("stage1_b64", "full3", "stage4_b8")] == [1, 2, 4]
+
+
 def test_golden_fixtures_are_data_only():
     for f in os.listdir(GOLDEN):
         if f.endswith(".npz"):
