@@ -305,7 +305,7 @@ struct P16Plan {
     int px2;                            // GK 1 on a stride-2 lattice: both column-parity classes in one workgroup (grid classes = row parities)
     int wc, lp;                         // cout fragments per wave (1, or 2: the 64 x 128 register tile); log2 of the lattice points per workgroup tile
     size_t slab, ws_bytes;
-    FastDiv dNXB, dPH, dTB;
+    FastDiv dNXB, dPH, dTB, dNT, dNCLS, dMT, dTX, dTY;
 };
 P16Plan plan_p16(const Geom& g, bool in16);
 void launch_p16_gather(const void* in, const void* wk, const float* bias, void* dst, const Geom& g, const P16Plan& p, int prec, int act,

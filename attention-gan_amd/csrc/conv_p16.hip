@@ -150,15 +150,20 @@ __global__ __launch_bounds__(256, (WC == 2 ? 1 : AGAN_P16_OCC)) void conv_p16_ke
     const int ksplit = pp.ksplit;
     int mt, nt, cls, split;
     {
+        // (divisions by the plan's tile counts as multiply-high with host-made constants: seven runtime scalar divisions were ~250 of the
+        //  360 instructions in front of the kernel's first load)
         const int ncls = pp.ncls, mtiles = pp.mtiles, ntiles = pp.ntiles;
         int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * ncls * ksplit);
-        nt = F % ntiles; F /= ntiles;
-        cls = F % ncls;  F /= ncls;
-        mt = F % mtiles; split = F / mtiles;
+        int q = pp.dNT.div(F);
+        nt = F - q * ntiles; F = q;
+        q = pp.dNCLS.div(F);
+        cls = F - q * ncls; F = q;
+        split = pp.dMT.div(F);
+        mt = F - split * mtiles;
     }
     const int py = PX2 ? cls : cls / g.OS, px = PX2 ? 0 : cls - py * g.OS;       // (PX2: the grid's classes are the ROW parities)
     const int n0 = nt * BN;
-    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+    const int mty = pp.dTX.div(mt), txi = mt - mty * pp.tiles_x, tbi = pp.dTY.div(mty), tyi = mty - tbi * pp.tiles_y;
     const int twl = pp.twl, thl = pp.thl;
     const int tb0 = tbi << (LP - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
     const int ihw = g.IH * g.IW;
@@ -226,6 +231,37 @@ __global__ __launch_bounds__(256, (WC == 2 ? 1 : AGAN_P16_OCC)) void conv_p16_ke
         if ((it_oct[i] < CHS / 8) & ((unsigned)xl < (unsigned)pp.PW)) *reinterpret_cast<u32x4*>(dstbuf + a) = v;
     };
 
+    // packed weights (conv_patch.hip): q = ((chunk32 * NPH + phase) * NT' + tap') * 2 + half
+    auto wq_of = [&](int stage, int u) {
+        if (GK == 0) return stage * 18 + u;                                   // chunk32 = stage; u = tap * 2 + half
+        if (GK == 1) return stage * 16 + u;                                   // two chunk32 per stage; u = c32 * 8 + tap * 2 + half
+        const int r = u >> 2, s = u & 3;                                      // GK 2: stage = (chunk32, half); u = tap (r, s)
+        const int ph = (r & 1) * 2 + (s & 1), tp = (r >> 1) * 2 + (s >> 1);
+        return (((stage >> 1) * 4 + ph) * 4 + tp) * 2 + (stage & 1);
+    };
+    // weight fragment f of a wave: PX2 -> class f (same 32 channels); WC 2 -> channels n0 + (wn * WC + f) * 32 ..
+    unsigned wlane[NWF];
+#pragma unroll
+    for (int f = 0; f < NWF; ++f)
+        wlane[f] = PX2 ? (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16) + (unsigned)(f * wbytes_cls)
+                       : (unsigned)(min(n0 + (wn * WC + f) * 32 + l31, g.Nld - 1) * 32 + lh * 16);
+    const unsigned wstep = (unsigned)(g.Nld * 32);
+    u32x4 wf[WD][NWF];
+    auto load_w = [&](int slot, int q) {
+#pragma unroll
+        for (int c = 0; c < NWF; ++c) wf[slot][c] = ld16(rwk, AGAN_P16_ABLATE == 2 ? kOOB : wlane[c], (unsigned)min(q, pp.wsteps - 1) * wstep);
+    };
+
+    // The first stage's patch and the first weight fragments are requested HERE, before the ~250 instructions of operand addressing below
+    // (fragment bases, tap offsets): the prologue was index math, THEN the loads, THEN ~1 us of HBM latency with nothing to do
+    // (first loads at instruction 444 of the kernel: round-4 ISA; the prologue is 17 % of a tile's life).
+    if (stage_beg < stage_end) {
+        load_items(stage_beg);
+#pragma unroll
+        for (int d = 0; d < WD; ++d) load_w(d, wq_of(stage_beg, d));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- MFMA operand addressing ----
     // fragment t of a wave: lattice points lat(t) * 32 + l31 (PX2: fragments 2f, 2f + 1 = classes px 0, 1 of lattice fragment f)
     auto lat_of = [&](int t) { return PX2 ? (wm * TM + t) >> 1 : wm * TM + t; };
@@ -250,27 +286,6 @@ __global__ __launch_bounds__(256, (WC == 2 ? 1 : AGAN_P16_OCC)) void conv_p16_ke
     // k-step u of a stage -> (tap, byte offset of its 16 channels inside a position, k-step of the packed weights)
     auto tap_of = [&](int u) { return GK == 2 ? u : (GK == 0 ? u / 2 : (u & 7) / 2); };
     auto choff_of = [&](int u) { return GK == 2 ? 0 : (GK == 0 ? (u & 1) * 32 : (u >> 3) * 64 + (u & 1) * 32); };
-    // packed weights (conv_patch.hip): q = ((chunk32 * NPH + phase) * NT' + tap') * 2 + half
-    auto wq_of = [&](int stage, int u) {
-        if (GK == 0) return stage * 18 + u;                                   // chunk32 = stage; u = tap * 2 + half
-        if (GK == 1) return stage * 16 + u;                                   // two chunk32 per stage; u = c32 * 8 + tap * 2 + half
-        const int r = u >> 2, s = u & 3;                                      // GK 2: stage = (chunk32, half); u = tap (r, s)
-        const int ph = (r & 1) * 2 + (s & 1), tp = (r >> 1) * 2 + (s >> 1);
-        return (((stage >> 1) * 4 + ph) * 4 + tp) * 2 + (stage & 1);
-    };
-    // weight fragment f of a wave: PX2 -> class f (same 32 channels); WC 2 -> channels n0 + (wn * WC + f) * 32 ..
-    unsigned wlane[NWF];
-#pragma unroll
-    for (int f = 0; f < NWF; ++f)
-        wlane[f] = PX2 ? (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16) + (unsigned)(f * wbytes_cls)
-                       : (unsigned)(min(n0 + (wn * WC + f) * 32 + l31, g.Nld - 1) * 32 + lh * 16);
-    const unsigned wstep = (unsigned)(g.Nld * 32);
-    u32x4 wf[WD][NWF];
-    auto load_w = [&](int slot, int q) {
-#pragma unroll
-        for (int c = 0; c < NWF; ++c) wf[slot][c] = ld16(rwk, AGAN_P16_ABLATE == 2 ? kOOB : wlane[c], (unsigned)min(q, pp.wsteps - 1) * wstep);
-    };
-
     f32x16 acc[WC][TM];
 #pragma unroll
     for (int c = 0; c < WC; ++c)
@@ -280,9 +295,6 @@ __global__ __launch_bounds__(256, (WC == 2 ? 1 : AGAN_P16_OCC)) void conv_p16_ke
             for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
     if (stage_beg < stage_end) {
-#pragma unroll
-        for (int d = 0; d < WD; ++d) load_w(d, wq_of(stage_beg, d));
-        load_items(stage_beg);
 #pragma unroll
         for (int w = 0; w < NWR; ++w) store_piece(w, lds + (stage_beg & 1) * buf_bytes);
         lds_barrier();
@@ -674,6 +686,11 @@ static P16Plan plan_impl(const Geom& g, bool in16, bool allow_px2, int tile = 0)
     p.dNXB = make_fastdiv((unsigned)p.NXB);
     p.dPH = make_fastdiv((unsigned)p.PH);
     p.dTB = make_fastdiv((unsigned)p.TB);
+    p.dNT = make_fastdiv((unsigned)p.ntiles);
+    p.dNCLS = make_fastdiv((unsigned)p.ncls);
+    p.dMT = make_fastdiv((unsigned)p.mtiles);
+    p.dTX = make_fastdiv((unsigned)p.tiles_x);
+    p.dTY = make_fastdiv((unsigned)p.tiles_y);
     p.ok = 1;
     return p;
 }
