@@ -281,6 +281,9 @@ struct PatchPlan {
     int tappos[9];                      // the same in positions
     int base_y[2][2], base_x[2][2];     // [output parity class][phase parity]: input coordinate of patch row/col 0 = IS * tile origin + base
     FastDiv dPP, dPHW, dPW;
+    // tile decode of the gather kernel without runtime scalar divisions (round 4; set by launch_patch_gather for the launch's grid)
+    FastDiv dNT, dNCLS, dMT, dTX, dTY, dNPH, dNPH2;
+    int g_ntiles, g_ncls;
 };
 struct PatchGather {
     int bn, ntiles, ncls, ksplit, stages_per_split;

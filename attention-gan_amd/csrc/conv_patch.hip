@@ -95,15 +95,20 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     const int l31 = lane & 31, lh = lane >> 5;
     int mt, nt, cls, split;
     {
-        const int ncls = gridDim.z / ksplit, mtiles = gridDim.x, ntiles = gridDim.y;
+        // (multiply-high with host-made constants instead of runtime scalar divisions, ~25 instructions each: with the stage decode below
+        //  there were nine of them among the ~560 instructions in front of the kernel's first load -- round 4)
+        const int ncls = pp.g_ncls, mtiles = gridDim.x, ntiles = pp.g_ntiles;
         int F = xcd_contiguous(linear_block_id(), mtiles * ntiles * (int)gridDim.z);
-        nt = F % ntiles; F /= ntiles;
-        cls = F % ncls;  F /= ncls;
-        mt = F % mtiles; split = F / mtiles;
+        int q = pp.dNT.div(F);
+        nt = F - q * ntiles; F = q;
+        q = pp.dNCLS.div(F);
+        cls = F - q * ncls; F = q;
+        split = pp.dMT.div(F);
+        mt = F - split * mtiles;
     }
-    const int py = cls / g.OS, px = cls - py * g.OS;
+    const int py = cls >= g.OS ? 1 : 0, px = cls - py * g.OS;           // (OS <= 2)
     const int n0 = nt * BN;
-    const int txi = mt % pp.tiles_x, tyi = (mt / pp.tiles_x) % pp.tiles_y, tbi = mt / (pp.tiles_x * pp.tiles_y);
+    const int mty = pp.dTX.div(mt), txi = mt - mty * pp.tiles_x, tbi = pp.dTY.div(mty), tyi = mty - tbi * pp.tiles_y;
     const int twl = pp.twl, thl = pp.thl;
     const int tb0 = tbi << (7 - twl - thl), ty0 = tyi << thl, tx0 = txi << twl;
     const int ihw = g.IH * g.IW;
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
     auto set_wq = [&](Stage& S) { S.wq = (S.chunk * pp.NPH + S.ph) * NT * 2 + (HS == 2 ? 0 : S.half); };
     auto stage_of = [&](int st) {
         Stage S;
-        if (HS == 2) { S.chunk = st / pp.NPH; S.ph = st - S.chunk * pp.NPH; S.half = 0; }
-        else { S.chunk = st / (2 * pp.NPH); const int rem = st - S.chunk * 2 * pp.NPH; S.half = rem / pp.NPH; S.ph = rem - S.half * pp.NPH; }
+        if (HS == 2) { S.chunk = pp.dNPH.div(st); S.ph = st - S.chunk * pp.NPH; S.half = 0; }
+        else { S.chunk = pp.dNPH2.div(st); const int rem = st - S.chunk * 2 * pp.NPH; S.half = rem >= pp.NPH ? 1 : 0; S.ph = rem - S.half * pp.NPH; }
         set_wq(S);
         return S;
     };
@@ -188,13 +193,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
         }
     };
 
-    unsigned lbase[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int l = (wm * TM + t) * 32 + l31;
-        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
-        lbase[t] = (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * PB + lh * 16);
-    }
     const unsigned wlane = (unsigned)(min(n0 + wn * 32 + l31, g.Nld - 1) * 32 + lh * 16);
     const unsigned wstep = (unsigned)(NPL * g.Nld * 32);
     // k-step of the packed weights for (stage, tap, 16-channel sub-step): taps are 2 k-steps apart, the sub-step is the low bit
@@ -205,6 +203,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
 #pragma unroll
         for (int p = 0; p < NPL; ++p) wf[slot][p] = buf_load_u4s(rwk, wlane, so + (unsigned)(p * g.Nld * 32));
     };
+    // the first stage's patch and the first weight fragments are requested HERE, ahead of the fragment addressing below: the HBM latency
+    // of a workgroup's first loads then runs under that index math instead of after it (conv_p16.hip, round 4: -6..-13 % per kernel)
+    Stage cs = stage_of(stage_beg);
+    if (stage_beg < stage_end) {
+        load_patch(cs);
+#pragma unroll
+        for (int d = 0; d < WD; ++d) load_w(d, qof(cs, d / HS, d % HS));       // (WD <= k-steps per stage)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned lbase[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int l = (wm * TM + t) * 32 + l31;
+        const int tx = l & ((1 << twl) - 1), ty = (l >> twl) & ((1 << thl) - 1), tb = l >> (twl + thl);
+        lbase[t] = (unsigned)(((tb * pp.PH + ty) * pp.PW + tx) * PB + lh * 16);
+    }
 
     f32x16 acc[TM];
 #pragma unroll
@@ -213,10 +227,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel2(const float* __rest
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (stage_beg < stage_end) {
-        Stage cs = stage_of(stage_beg);
-#pragma unroll
-        for (int d = 0; d < WD; ++d) load_w(d, qof(cs, d / HS, d % HS));       // (WD <= k-steps per stage)
-        load_patch(cs);
 #pragma unroll
         for (int i = 0; i < NI; ++i) store_item(i, patch2 + (stage_beg & 1) * buf_bytes);
         lds_barrier();
@@ -1053,8 +1063,13 @@ __global__ __launch_bounds__(256) void pack_patch_jobs_kernel(const agan_pack_jo
 }
 
 template <int ET, int NPL, int BN>
-void launch_nt(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp, const PatchGather& p,
+void launch_nt(const float* in, const void* wk, const float* bias, float* dst, const Geom& g, const PatchPlan& pp_in, const PatchGather& p,
                int act, const float* mask, hipStream_t st, const float* in_scale, float* out_amax) {
+    PatchPlan pp = pp_in;                 // + the multiply-high constants of this launch's tile decode
+    pp.g_ntiles = p.ntiles; pp.g_ncls = p.ncls;
+    pp.dNT = make_fastdiv((unsigned)p.ntiles); pp.dNCLS = make_fastdiv((unsigned)p.ncls); pp.dMT = make_fastdiv((unsigned)pp.mtiles);
+    pp.dTX = make_fastdiv((unsigned)pp.tiles_x); pp.dTY = make_fastdiv((unsigned)pp.tiles_y);
+    pp.dNPH = make_fastdiv((unsigned)pp.NPH); pp.dNPH2 = make_fastdiv((unsigned)(2 * pp.NPH));
     dim3 grid(pp.mtiles, p.ntiles, p.ncls * p.ksplit);
     const unsigned short* w = static_cast<const unsigned short*>(wk);
     constexpr int PB = (NPL >= 3 ? 16 : 32) * 2 + 16;
