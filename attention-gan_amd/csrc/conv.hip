@@ -374,7 +374,87 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel_t(const float* __restric
     }
     if (amax) amax_commit(mx, amax);
 }
-#define sum_slabs_kernel sum_slabs_kernel_t<AGAN_DT_F32>      /* the fp32 form every fp32-storage call site uses */
+// The same sum for FEW slabs (nsplit <= 8: every K split of a gather, most pixel splits of the large weight gradients).  The kernel above
+// gives each of its 8 thread groups every 8th slab: with 2-4 slabs three quarters of a workgroup load nothing and every 512 bytes of a slab
+// cost two barriers -- 0.3-1.1 TB/s on the 6-75 MB sums that make up two thirds of the step's slab time (round-4 kernel trace).  Here a thread
+// owns one float4 of the result, has all its slab loads in flight at once and adds them in slab order -- the order the grouped kernel
+// produces for nsplit <= 8, so results are bit-identical.
+template <int ODT>
+__global__ __launch_bounds__(256) void sum_slabs_few_kernel_t(const float* __restrict__ ws, int nsplit, size_t n, size_t slab,
+                                                              const float* __restrict__ bias, int C, int HW,
+                                                              void* __restrict__ out, int accumulate, int act = AGAN_ACT_NONE,
+                                                              const void* __restrict__ lrelu_mask = nullptr, float* __restrict__ amax = nullptr) {
+    float mx = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float* p = ws + i * 4;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nsplit) {
+                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)k * slab));      // (read exactly once)
+                v[k] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        float4 a = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < nsplit) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+        if (bias) {
+            const size_t q = i * 4;
+            a.x += bias[(q / HW) % C]; a.y += bias[((q + 1) / HW) % C];
+            a.z += bias[((q + 2) / HW) % C]; a.w += bias[((q + 3) / HW) % C];
+        }
+        if (accumulate) {
+            const float4 o = ld4<ODT>(out, i * 4);
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        if (act == AGAN_ACT_LRELU) {
+            a.x = a.x > 0.f ? a.x : 0.2f * a.x; a.y = a.y > 0.f ? a.y : 0.2f * a.y;
+            a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w;
+        }
+        if (lrelu_mask) {
+            const float4 m = ld4<ODT>(lrelu_mask, i * 4);
+            a.x = m.x > 0.f ? a.x : 0.2f * a.x; a.y = m.y > 0.f ? a.y : 0.2f * a.y;
+            a.z = m.z > 0.f ? a.z : 0.2f * a.z; a.w = m.w > 0.f ? a.w : 0.2f * a.w;
+        }
+        st4<ODT>(out, i * 4, a);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // tail (n not a multiple of 4)
+        const size_t q = n4 * 4 + threadIdx.x;
+        float a = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * slab + q];
+        if (bias) a += bias[(q / HW) % C];
+        if (accumulate) a += ld1<ODT>(out, q);
+        if (act == AGAN_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
+        if (lrelu_mask) a = ld1<ODT>(lrelu_mask, q) > 0.f ? a : 0.2f * a;
+        st1<ODT>(out, q, a);
+        mx = fmaxf(mx, fabsf(a));
+    }
+    if (amax) amax_commit(mx, amax);
+}
+
+// out = sum of nsplit slabs (+ bias, + out, activation, mask), ODT = storage type of out / lrelu_mask
+template <int ODT>
+void launch_sum_slabs_t(const float* ws, int nsplit, size_t n, size_t slab, const float* bias, int C, int HW, void* out, int accumulate,
+                        int act, const void* lrelu_mask, float* amax, hipStream_t st) {
+    static const bool few_off = getenv("AGAN_SUM_FEW_OFF") != nullptr;          // (A/B switch)
+    if (nsplit <= 8 && !few_off) {
+        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 256), 32768);
+        AGAN_LAUNCH(sum_slabs_few_kernel_t<ODT>, dim3(blocks), dim3(256), 0, st, ws, nsplit, n, slab, bias, C, HW, out, accumulate, act,
+                    lrelu_mask, amax);
+    } else {
+        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
+        AGAN_LAUNCH(sum_slabs_kernel_t<ODT>, dim3(blocks), dim3(256), 0, st, ws, nsplit, n, slab, bias, C, HW, out, accumulate, act,
+                    lrelu_mask, amax);
+    }
+}
+void launch_sum_slabs(const float* ws, int nsplit, size_t n, size_t slab, const float* bias, int C, int HW, void* out, int accumulate,
+                      int act, const void* lrelu_mask, float* amax, hipStream_t st, int out_dtype = AGAN_DT_F32) {
+    if (out_dtype == AGAN_DT_F32) launch_sum_slabs_t<AGAN_DT_F32>(ws, nsplit, n, slab, bias, C, HW, out, accumulate, act, lrelu_mask, amax, st);
+    else if (out_dtype == AGAN_DT_BF16) launch_sum_slabs_t<AGAN_DT_BF16>(ws, nsplit, n, slab, bias, C, HW, out, accumulate, act, lrelu_mask, amax, st);
+    else launch_sum_slabs_t<AGAN_DT_F16>(ws, nsplit, n, slab, bias, C, HW, out, accumulate, act, lrelu_mask, amax, st);
+}
 
 template <int BN, int WM, int WN>
 void launch_gather(const float* in, const float* wk, const float* bias, void* dst, const int2* ktab, const Geom& g,
@@ -1021,13 +1101,8 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
             if (int e = check_launch("conv_gather/p16")) return e;
             if (p16.ksplit > 1) {
                 const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
-                const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-#define AGAN_SUM_DT(DT) AGAN_LAUNCH(sum_slabs_kernel_t<DT>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p16.ksplit, n, \
-                                           p16.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v, (float*)nullptr)
-                if (out_dtype == AGAN_DT_F32) AGAN_SUM_DT(AGAN_DT_F32);
-                else if (out_dtype == AGAN_DT_BF16) AGAN_SUM_DT(AGAN_DT_BF16);
-                else AGAN_SUM_DT(AGAN_DT_F16);
-#undef AGAN_SUM_DT
+                launch_sum_slabs(static_cast<const float*>(ws), p16.ksplit, n, p16.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v,
+                                 nullptr, st, out_dtype);
                 return check_launch("conv_gather/p16/sum_slabs");
             }
             return AGAN_OK;
@@ -1054,9 +1129,7 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
         if (int e = check_launch("conv_gather/patch")) return e;
         if (p.ksplit > 1) {
             const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
-            const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-            AGAN_LAUNCH(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, p.slab,
-                               bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask, out_amax);
+            launch_sum_slabs(static_cast<const float*>(ws), p.ksplit, n, p.slab, bias, g.Cout, g.OH * g.OW, out, 0, act, lrelu_mask, out_amax, st);
             return check_launch("conv_gather/sum_slabs");
         }
         return AGAN_OK;
@@ -1075,9 +1148,8 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
             if (int e = check_launch("conv_gather/winograd")) return e;
             if (wp.ksplit > 1) {
                 const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
-                AGAN_LAUNCH(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st,
-                                   reinterpret_cast<const float*>(static_cast<const char*>(ws) + wp.u_bytes), wp.ksplit, n, wp.slab, (const float*)nullptr,
-                                   g.Cout, g.OH * g.OW, out, 0, AGAN_ACT_NONE, (const void*)nullptr, (float*)nullptr);
+                launch_sum_slabs(reinterpret_cast<const float*>(static_cast<const char*>(ws) + wp.u_bytes), wp.ksplit, n, wp.slab, nullptr,
+                                 g.Cout, g.OH * g.OW, out, 0, AGAN_ACT_NONE, nullptr, nullptr, st);
                 return check_launch("conv_gather/winograd/sum_slabs");
             }
             return AGAN_OK;
@@ -1103,13 +1175,8 @@ int agan_conv_gather_dt(const void* in_v, const void* wkv, const float* bias, vo
     if (int e = check_launch("conv_gather")) return e;
     if (p.ksplit > 1) {
         const size_t n = (size_t)g.B * g.Cout * g.OH * g.OW;
-        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-#define AGAN_SUM_DT(DT) AGAN_LAUNCH(sum_slabs_kernel_t<DT>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), p.ksplit, n, \
-                                           p.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v, (float*)nullptr)
-        if (out_dtype == AGAN_DT_F32) AGAN_SUM_DT(AGAN_DT_F32);
-        else if (out_dtype == AGAN_DT_BF16) AGAN_SUM_DT(AGAN_DT_BF16);
-        else AGAN_SUM_DT(AGAN_DT_F16);
-#undef AGAN_SUM_DT
+        launch_sum_slabs(static_cast<const float*>(ws), p.ksplit, n, p.slab, bias, g.Cout, g.OH * g.OW, out_v, 0, act, lrelu_mask_v, nullptr, st,
+                         out_dtype);
         return check_launch("conv_gather/sum_slabs");
     }
     return AGAN_OK;
@@ -1228,8 +1295,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
             if (rp.psplit > 4) {
                 float* reduced = wsf + rp.slab * rp.psplit;
                 const size_t n = (size_t)g.Cout * rp.Kp;
-                AGAN_LAUNCH(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, rp.psplit, n,
-                                   rp.slab, (const float*)nullptr, 1, 1, reduced, 0);
+                launch_sum_slabs(wsf, rp.psplit, n, rp.slab, nullptr, 1, 1, reduced, 0, AGAN_ACT_NONE, nullptr, nullptr, st);
                 if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
                 src = reduced;
                 nsl = 1;
@@ -1260,8 +1326,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
         }
         if (p.psplit > 1) {
             const size_t n = (size_t)p.ncls * g.Cout * p.Kp;
-            AGAN_LAUNCH(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, wsf, p.psplit, n,
-                               p.slab, (const float*)nullptr, 1, 1, reduced, 0);
+            launch_sum_slabs(wsf, p.psplit, n, p.slab, nullptr, 1, 1, reduced, 0, AGAN_ACT_NONE, nullptr, nullptr, st);
             if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
         }
         if (!up) launch_wgrad_sum_unpack(reduced, 1, p.slab, dw, g.Cout, g.Cin, kh, kw, pp.NPH, pp.NT, p.Kp, accumulate, st);
@@ -1279,8 +1344,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
         launch_wgrad_small_n(x_v, dy, part, g, sp, st, x_dtype);
         timer_end(st);
         const size_t n = (size_t)g.Cout * g.K;
-        AGAN_LAUNCH(sum_slabs_kernel, dim3((unsigned)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192)), dim3(256), 0, st, part, sp.nchunk,
-                           n, sp.slab, (const float*)nullptr, 1, 1, dw, accumulate);
+        launch_sum_slabs(part, sp.nchunk, n, sp.slab, nullptr, 1, 1, dw, accumulate, AGAN_ACT_NONE, nullptr, nullptr, st);
         return check_launch("conv_wgrad/small_n");
     }
     const WgradPlan p = plan_wgrad(g, up);
@@ -1309,9 +1373,7 @@ int agan_conv_wgrad_dt(const void* x_v, const void* dy_v, float* dw, const agan_
     if (int e = check_launch("conv_wgrad")) return e;
     const size_t n = (size_t)p.ncls * g.Cout * g.K;
     if (via_sum) {
-        const int blocks = (int)std::min<size_t>(cdivz(n / 4 + 1, 32), 8192);
-        AGAN_LAUNCH(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, p.psplit, n, p.slab, (const float*)nullptr, 1, 1, reduced,
-                           (accumulate && !up) ? 1 : 0);
+        launch_sum_slabs(part, p.psplit, n, p.slab, nullptr, 1, 1, reduced, (accumulate && !up) ? 1 : 0, AGAN_ACT_NONE, nullptr, nullptr, st);
         if (int e = check_launch("conv_wgrad/sum_slabs")) return e;
     }
     if (up) {
