@@ -190,3 +190,62 @@ def _run_metric_parity(bench, HF, mode):
     for k in hip:
         if not k.startswith(("gG/", "gD")):
             assert rel_err(hip[k], o32[k]) <= RTOL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_metric_config_step_is_bit_stable_run_to_run(mode):
+    """The same first step from the same weights and inputs, four times: fake images, the gradients w.r.t. the three fake images and
+    every generator gradient must be IDENTICAL bit for bit.  The step runs its three discriminators on three streams, so kernels of
+    different launches share compute units -- the condition under which a first version of the <= 4-channel strip kernels
+    (csrc/conv_small.hip: v_pk_fma_f32 taking an operand from the high dword of a register pair) returned different low-half results
+    in lanes 48-63 from run to run, although each launch in isolation was bit-stable (round 4).  The oracle comparison above only
+    caught that in about half of its runs; this test does not depend on luck."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    HF = importlib.import_module("attention-gan_amd.backend.functional")
+    LIB = importlib.import_module("attention-gan_amd.backend.lib")
+    HF.set_precision(LIB.PRECISIONS[mode])
+    try:
+        B = 24
+        g = torch.Generator().manual_seed(2024)
+        lens = torch.randint(2, 11, (B,), generator=g).tolist()
+        lens[3] = bench.T
+        data = dict(words=torch.randn(B, bench.EMB, bench.T, generator=g), sent=torch.randn(B, bench.EMB, generator=g),
+                    reals=[torch.rand(B, 3, r, r, generator=g) * 2 - 1 for r in (64, 128, 256)],
+                    noise=torch.randn(B, bench.Z, generator=g), eps=torch.randn(B, bench.COND, generator=g))
+        to = lambda t: t.to(DEV)
+        base = None
+        for run in range(4):
+            step = bench.build(torch.device(DEV), B, HF)
+            cap = {}
+            orig = step.gen_loss.get_loss
+
+            def wrapped(d, fake, _orig=orig, _cap=cap):
+                i = sum(1 for k in _cap if k.startswith("seen"))
+                _cap[f"seen{i}"] = True
+                fake.register_hook(lambda gr, i=i: _cap.__setitem__(f"dfake{i}", gr.detach().clone()))
+                return _orig(d, fake)
+            step.gen_loss.get_loss = wrapped
+
+            def grab(tag, opt, _cap=cap, _step=step):
+                if tag == "G":
+                    for k, v in opt.named_gradients(_step.G).items():
+                        _cap[f"gG/{k}"] = v.detach().clone()
+            step.on_gradients = grab
+            out = step.step(to(data["words"]), to(data["sent"]), lens, None, [to(r) for r in data["reals"]], to(data["noise"]), to(data["eps"]))
+            torch.cuda.synchronize()
+            cur = {k: v.cpu() for k, v in cap.items() if torch.is_tensor(v)}
+            for i in range(3):
+                cur[f"fake{i}"] = out["fake_imgs"][i].cpu()
+            del step, out
+            torch.cuda.empty_cache()
+            if base is None:
+                base = cur
+                assert {"dfake0", "dfake1", "dfake2"} <= set(base)
+                continue
+            diff = [f"{k}: {int((base[k] != cur[k]).sum())} of {base[k].numel()} elements, max rel {rel_err(cur[k], base[k]):.2e}"
+                    for k in sorted(base) if not torch.equal(base[k], cur[k])]
+            assert not diff, f"run {run} differs from run 0:\n" + "\n".join(diff)
+    finally:
+        HF.set_precision(LIB.PREC_F32)

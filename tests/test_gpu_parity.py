@@ -422,6 +422,50 @@ def test_conv_engine_random_shapes_vs_torch_cpu():
         done += 1
 
 
+# Row-strip kernels of the <= 4-channel convs (csrc/conv_small.hip, round 4): 3x3 heads forward + weight gradient, the 4-class data gradient of
+# conv4x4-s2 w.r.t. a <= 4-channel image.  Row widths: 16 .. 256 pixels (rows never straddle a wave), 48 / 24 (rows change inside a wave at
+# arbitrary lanes) and 512 (a row spans two waves: the first / last lane's halo pixel comes from memory).
+STRIP_CASES = [
+    # kind, B, Cin, H, W, Cout
+    ("same", 2, 32, 64, 64, 3),
+    ("same", 1, 5, 128, 128, 3),
+    ("same", 3, 8, 16, 16, 1),
+    ("same", 2, 4, 32, 48, 4),
+    ("same", 1, 3, 8, 512, 3),
+    ("same", 2, 6, 24, 256, 2),
+    ("down", 2, 3, 64, 64, 16),
+    ("down", 1, 3, 16, 48, 8),
+    ("down", 2, 4, 32, 32, 8),
+    ("down", 1, 1, 16, 16, 8),
+    ("down", 1, 3, 8, 1024, 8),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,H,W,Cout", STRIP_CASES)
+def test_small_channel_strip_kernels_vs_torch_cpu(kind, B, Cin, H, W, Cout):
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
+    k = 3 if kind == "same" else 4
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if kind == "same" else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if b is not None else None
+    yr = F.conv2d(xr, wr, br, padding=1) if kind == "same" else F.conv2d(xr, wr, None, stride=2, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if b is not None else None
+    yd = HF.conv2d(xd, wd, bd, kind)
+    yd.backward(gy.to(DEV))
+    tag = f"{kind} B{B} {Cin}x{H}x{W}->{Cout}"
+    assert_close(yd, yr, RTOL, f"y {tag}")
+    assert_close(xd.grad, xr.grad, RTOL, f"dx {tag}")
+    assert_close(wd.grad, wr.grad, RTOL, f"dw {tag}")
+    if b is not None:
+        assert_close(bd.grad, br.grad, RTOL, f"db {tag}")
+
+
 def test_paired_discriminator_pass_equals_two_passes():
     """disc_loss.py:55-61 runs D(real) then D(fake).  NonSaturatingDiscLoss sends [real; fake] through once under bn_groups(2):
     loss, every parameter gradient and every BatchNorm buffer (two running-stat updates, real first; num_batches_tracked += 2)

@@ -68,6 +68,31 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("kind,B,Cin,H,W,Cout", [("same", 2, 32, 64, 64, 3), ("same", 1, 8, 16, 512, 3), ("down", 2, 3, 64, 64, 16), ("down", 1, 3, 16, 48, 8)])
+def test_small_channel_strip_kernels_read_16bit_storage(mode, kind, B, Cin, H, W, Cout):
+    """The <= 4-channel row-strip kernels (csrc/conv_small.hip) gather a 16-bit-stored tensor directly: the RGB head reads the 16-bit h_code
+    (fp32 image out), the image gradient of a discriminator's first conv reads the 16-bit dY."""
+    name, tdt, ulp = mode
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    q = lambda t: t.to(tdt).float()
+    k = 3 if kind == "same" else 4
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = _ref_conv(kind, xr, wr, None)
+    gy = q(probe(yr.shape, 0.3))
+    yr.backward(gy)
+    in16 = kind == "same"                      # (the first discriminator conv reads the fp32 image)
+    xd = (x.to(tdt) if in16 else x).to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y = HF.conv2d(xd, wd, None, kind)
+    y.backward(gy.to(DEV).to(y.dtype))
+    tol = 1.5 * ulp
+    assert_close(y.float(), yr, tol, "fwd")
+    assert_close(xd.grad.float(), xr.grad, tol, "dgrad")
+    assert_close(wd.grad, wr.grad, max(tol / 4, 2e-4), "wgrad")
+
+
 @pytest.mark.parametrize("kind,B,Cin,H,W,Cout,k,in16", CASES)
 def test_conv_with_16bit_storage_vs_torch(mode, kind, B, Cin, H, W, Cout, k, in16):
     name, tdt, ulp = mode
