@@ -192,11 +192,10 @@ def _run_metric_parity(bench, HF, mode):
             assert rel_err(hip[k], o32[k]) <= RTOL, k
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16+s16"])
 def test_metric_config_step_is_bit_stable_run_to_run(mode):
     """The same first step from the same weights and inputs, four times: fake images, the gradients w.r.t. the three fake images and
-    every generator gradient must be IDENTICAL bit for bit.  The step runs its three discriminators on three streams, so kernels of
+    every generator and discriminator gradient must be IDENTICAL bit for bit ("bf16+s16": bf16 arithmetic with 16-bit activation storage).  The step runs its three discriminators on three streams, so kernels of
     different launches share compute units -- the condition under which a first version of the <= 4-channel strip kernels
     (csrc/conv_small.hip: v_pk_fma_f32 taking an operand from the high dword of a register pair) returned different low-half results
     in lanes 48-63 from run to run, although each launch in isolation was bit-stable (round 4).  The oracle comparison above only
@@ -205,7 +204,8 @@ def test_metric_config_step_is_bit_stable_run_to_run(mode):
     import bench
     HF = importlib.import_module("attention-gan_amd.backend.functional")
     LIB = importlib.import_module("attention-gan_amd.backend.lib")
-    HF.set_precision(LIB.PRECISIONS[mode])
+    HF.set_precision(LIB.PRECISIONS[mode.split("+")[0]])
+    HF.set_activation_storage("bf16" if mode.endswith("+s16") else None)
     try:
         B = 24
         g = torch.Generator().manual_seed(2024)
@@ -229,9 +229,9 @@ def test_metric_config_step_is_bit_stable_run_to_run(mode):
             step.gen_loss.get_loss = wrapped
 
             def grab(tag, opt, _cap=cap, _step=step):
-                if tag == "G":
-                    for k, v in opt.named_gradients(_step.G).items():
-                        _cap[f"gG/{k}"] = v.detach().clone()
+                mod = _step.G if tag == "G" else _step.Ds[int(tag[1])]
+                for k, v in opt.named_gradients(mod).items():
+                    _cap[f"g{tag}/{k}"] = v.detach().clone()
             step.on_gradients = grab
             out = step.step(to(data["words"]), to(data["sent"]), lens, None, [to(r) for r in data["reals"]], to(data["noise"]), to(data["eps"]))
             torch.cuda.synchronize()
@@ -249,3 +249,4 @@ def test_metric_config_step_is_bit_stable_run_to_run(mode):
             assert not diff, f"run {run} differs from run 0:\n" + "\n".join(diff)
     finally:
         HF.set_precision(LIB.PREC_F32)
+        HF.set_activation_storage(None)
