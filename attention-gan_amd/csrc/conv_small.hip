@@ -184,12 +184,16 @@ __device__ __forceinline__ void strip_setup(bool valid, int b, int y, int xs, in
 }
 
 // 3x3 / stride 1 / pad 1 with NC <= 4 output channels (the RGB heads, generator_submodules.py:135)
-template <int IDT, int NC>
+// CS (channel split, 1 or 4): on small images the grid is a few hundred waves, each a dependent chain over all Cin channels (the 64 x 64 head ran the
+// same 22 us as the 128 x 128 one) -- with CS = 4 the four waves of a workgroup share 64 strips, wave w takes channels w, w + 4, ... and the partial sums
+// meet in LDS in wave order (a fixed order: results do not depend on timing).
+template <int IDT, int NC, int CS>
 __global__ __launch_bounds__(256) void conv_small_strip_kernel(const void* __restrict__ in, const float* __restrict__ wk,
                                                                const float* __restrict__ bias, float* __restrict__ out, const Geom g) {
     const int W4 = g.IW >> 2;
     const int nstrips = g.B * g.IH * W4;
-    const int sid = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int sid = CS == 1 ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 64 + (threadIdx.x & 63);
     const bool valid = sid < nstrips;
     const int ss = valid ? sid : 0;
     const int xs = ss % W4, t1 = ss / W4, y = t1 % g.IH, b = t1 / g.IH;
@@ -207,17 +211,18 @@ __global__ __launch_bounds__(256) void conv_small_strip_kernel(const void* __res
     // wave-uniform s_load_dwordx4 they were fetched two at a time right in front of their use, a scalar-cache miss each
     __shared__ float4 wl[kStripCh * 9];
     u32x4s raw[3];
-    strip_issue<IDT>(rin, off4, 0u, raw);
+    const int cfirst = CS == 1 ? 0 : wave;              // this wave's channels: cfirst, cfirst + CS, ...  (kStripCh is a multiple of CS)
+    if (cfirst < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)(cfirst * ihw), raw);
     for (int c0 = 0; c0 < g.Cin; c0 += kStripCh) {
         const int nch = min(kStripCh, g.Cin - c0);
         __syncthreads();
         for (int i = threadIdx.x; i < nch * 9; i += 256) wl[i] = *reinterpret_cast<const float4*>(wk + (size_t)(c0 * 9 + i) * g.Nld);
         __syncthreads();
-        for (int cc = 0; cc < nch; ++cc) {
+        for (int cc = cfirst; cc < nch; cc += CS) {
             const int c = c0 + cc;
             float v[3][6];
             strip_finish<IDT>(rin, raw, h, (unsigned)(c * ihw), v);
-            if (c + 1 < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)((c + 1) * ihw), raw);
+            if (c + CS < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)((c + CS) * ihw), raw);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -230,6 +235,25 @@ __global__ __launch_bounds__(256) void conv_small_strip_kernel(const void* __res
                         for (int n = 0; n < NC; ++n) acc[p][n] += w[n] * v[r][p + t];
                 }
         }
+    }
+    if (CS > 1) {
+        __shared__ float red[CS - 1 > 0 ? CS - 1 : 1][4 * NC][64];
+        const int lane = threadIdx.x & 63;
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < NC; ++n) red[wave - 1][p * NC + n][lane] = acc[p][n];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < CS - 1; ++w)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < NC; ++n) acc[p][n] += red[w][p * NC + n][lane];
     }
     if (!valid) return;
     float* o = out + ((size_t)b * g.Cout * g.IH + y) * g.IW + xs * 4;
@@ -246,12 +270,13 @@ __global__ __launch_bounds__(256) void conv_small_strip_kernel(const void* __res
 // lattice points of one lattice row and ALL FOUR classes -- the 2 x 8 output pixels they produce.  The classes' taps cover rows y' - 1 .. y' + 1
 // and columns x' - 1 .. x' + 1 of dY: the same three 6-pixel rows per channel as the 3x3 strip, loaded once instead of once per class and tap
 // (the per-pixel kernel above issued one 4-byte load per (class, channel, tap): 17 % of HBM peak, bound by its vector-memory instructions).
-template <int IDT, int NC>
+template <int IDT, int NC, int CS>
 __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void* __restrict__ in, const float* __restrict__ wk,
                                                                       const float* __restrict__ bias, float* __restrict__ out, const Geom g) {
     const int W4 = g.IW >> 2;
     const int nstrips = g.B * g.IH * W4;
-    const int sid = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int sid = CS == 1 ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 64 + (threadIdx.x & 63);
     const bool valid = sid < nstrips;
     const int ss = valid ? sid : 0;
     const int xs = ss % W4, t1 = ss / W4, y = t1 % g.IH, b = t1 / g.IH;
@@ -270,7 +295,8 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
     const size_t wcls = (size_t)g.K * g.Nld;            // K = Cin * 4
     __shared__ float4 wl[kStripCh * 16];                // [channel][class][r][t] x 4 floats
     u32x4s raw[3];
-    strip_issue<IDT>(rin, off4, 0u, raw);
+    const int cfirst = CS == 1 ? 0 : wave;
+    if (cfirst < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)(cfirst * ihw), raw);
     for (int c0 = 0; c0 < g.Cin; c0 += kStripCh) {
         const int nch = min(kStripCh, g.Cin - c0);
         __syncthreads();
@@ -279,11 +305,11 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
             wl[i] = *reinterpret_cast<const float4*>(wk + k * wcls + (size_t)((c0 + cc) * 4 + rt) * g.Nld);
         }
         __syncthreads();
-        for (int cc = 0; cc < nch; ++cc) {
+        for (int cc = cfirst; cc < nch; cc += CS) {
             const int c = c0 + cc;
             float v[3][6];
             strip_finish<IDT>(rin, raw, h, (unsigned)(c * ihw), v);
-            if (c + 1 < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)((c + 1) * ihw), raw);
+            if (c + CS < g.Cin) strip_issue<IDT>(rin, off4, (unsigned)((c + CS) * ihw), raw);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int py = k >> 1, px = k & 1;
@@ -301,6 +327,29 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
                     }
             }
         }
+    }
+    if (CS > 1) {
+        __shared__ float red[CS - 1 > 0 ? CS - 1 : 1][16 * NC][64];
+        const int lane = threadIdx.x & 63;
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) red[wave - 1][(k * 4 + p) * NC + n][lane] = acc[k][p][n];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < CS - 1; ++w)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) acc[k][p][n] += red[w][(k * 4 + p) * NC + n][lane];
     }
     if (!valid) return;
     // output rows 2 y' + py, columns 8 xs .. 8 xs + 7 = (x' = 4 xs + p, px) interleaved
@@ -515,31 +564,40 @@ void launch_gather_small_n(const void* in, const float* wk, const float* bias, f
         return;
     }
     if (strip_ok(g)) {
-        const dim3 sg(cdiv(g.B * g.IH * (g.IW >> 2), 256));
-#define AGAN_STRIP(NC_)                                                                                                                   \
+        // few strips (small images): split the channels over the four waves of a workgroup (the kernel's CS)
+        const int nstrips = g.B * g.IH * (g.IW >> 2);
+        const bool split = nstrips <= 64 * 1024 && g.Cin >= 8;      // (measured: at 1536 waves the split is neutral to slower)
+        const dim3 sg(split ? cdiv(nstrips, 64) : cdiv(nstrips, 256));
+#define AGAN_STRIP2(NC_, CS_)                                                                                                             \
     do {                                                                                                                                  \
-        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_BF16, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
-        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F16, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
-        else AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F32, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g);                       \
+        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_BF16, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
+        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F16, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
+        else AGAN_LAUNCH((conv_small_strip_kernel<AGAN_DT_F32, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g);                  \
     } while (0)
+#define AGAN_STRIP(NC_) do { if (split) AGAN_STRIP2(NC_, 4); else AGAN_STRIP2(NC_, 1); } while (0)
         if (g.Cout <= 2) AGAN_STRIP(2);
         else if (g.Cout == 3) AGAN_STRIP(3);
         else AGAN_STRIP(4);
 #undef AGAN_STRIP
+#undef AGAN_STRIP2
         return;
     }
     if (dgrad4_strip_ok(g)) {
-        const dim3 sg(cdiv(g.B * g.IH * (g.IW >> 2), 256));
-#define AGAN_STRIP(NC_)                                                                                                                   \
+        const int nstrips = g.B * g.IH * (g.IW >> 2);
+        const bool split = nstrips <= 64 * 1024 && g.Cin >= 8;      // (measured: at 1536 waves the split is neutral to slower)
+        const dim3 sg(split ? cdiv(nstrips, 64) : cdiv(nstrips, 256));
+#define AGAN_STRIP2(NC_, CS_)                                                                                                             \
     do {                                                                                                                                  \
-        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_BF16, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
-        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_F16, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
-        else AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_F32, NC_>), sg, dim3(256), 0, st, in, wk, bias, out, g);                \
+        if (in_dtype == AGAN_DT_BF16) AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_BF16, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
+        else if (in_dtype == AGAN_DT_F16) AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_F16, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g); \
+        else AGAN_LAUNCH((conv_small_dgrad4_strip_kernel<AGAN_DT_F32, NC_, CS_>), sg, dim3(256), 0, st, in, wk, bias, out, g);           \
     } while (0)
+#define AGAN_STRIP(NC_) do { if (split) AGAN_STRIP2(NC_, 4); else AGAN_STRIP2(NC_, 1); } while (0)
         if (g.Cout <= 2) AGAN_STRIP(2);
         else if (g.Cout == 3) AGAN_STRIP(3);
         else AGAN_STRIP(4);
 #undef AGAN_STRIP
+#undef AGAN_STRIP2
         return;
     }
     dim3 grid(cdiv(g.Mtot, 256), g.OS * g.OS);
