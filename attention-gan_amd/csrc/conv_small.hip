@@ -96,14 +96,15 @@ template <int DT> __device__ __forceinline__ float buf_load1_dt(const __amdgpu_b
 // wave's first / last lane from memory (`edge`, wave-uniform).  The NC <= 4 output channels are plain scalar accumulators -- one v_fmac_f32 per
 // channel, none for a dead fourth channel (the round-3 kernels always computed four).
 //
-// NO PACKED FP32 MATH IN THIS FILE (it is compiled with -fno-slp-vectorize, csrc/Makefile).  The first version of these kernels kept channel
-// pairs in float2 accumulators; the compiler turned the updates into v_pk_fma_f32 with the pixel broadcast by op_sel, and the eight instructions of
-// the image-gradient kernel that took it from the HIGH dword of a register pair (op_sel:[0,1,0]) gave run-to-run DIFFERENT low-half results in
-// lanes 48-63 when the kernel ran inside the train step (three discriminators on three streams; up to 7 % on single pixels of the image gradient,
-// 3e-3 on an RGB head's weight gradient -- tests/test_gpu_metric_parity.py[bf16x6] caught it) while the same launches in isolation, also three at
-// a time on three streams, were bit-stable over hundreds of runs.  Builds without those forms (scalar source packed by the SLP vectoriser over
-// pixel pairs: plain v_pk_fma_f32; and no packed math at all) are bit-stable in the step as well, and the scalar one is the fastest of the three
-// at 256 x 256: these kernels wait on memory, not on the vector ALU.  profiles/r04_p16_analysis.txt section 7, profiles/dev/step_repeat.py.
+// NO PACKED FP32 MATH (this file is compiled with -fno-slp-vectorize on top of the library-wide -packed-fp32-ops, csrc/Makefile).  The first version of
+// these kernels kept channel pairs in float2 accumulators; the compiler turned the updates into v_pk_fma_f32 with the pixel broadcast by op_sel, and the
+// eight instructions of the image-gradient kernel that took it from the HIGH dword of a register pair (op_sel:[0,1,0]) gave run-to-run DIFFERENT low-half
+// results in lanes 48-63 inside the bf16x6 train step (up to 7 % on single pixels of the image gradient, 3e-3 on an RGB head's weight gradient --
+// tests/test_gpu_metric_parity.py[bf16x6] caught it) while every launch in isolation was bit-stable.  Cause, reproduced without this library in
+// profiles/micro/pk_fma_coexec.hip: on this pool's MI355X exactly that instruction form returns wrong low halves in lanes 48-63 now and then while OTHER
+// waves of the compute unit issue v_mfma_f32_32x32x16_bf16 (the other discriminators' convolutions); next to fp32 MFMAs or on an idle chip it never does.
+// The scalar kernels below are also the fastest of the three builds measured at 256 x 256: they wait on memory, not on the vector ALU.
+// profiles/r04_p16_analysis.txt section 7; -DAGAN_STRIP_PACKED_PAIRS rebuilds the packed form of the image-gradient kernel for profiles/dev/dgrad4_stress4.py.
 constexpr int kStripCh = 64;        // channels whose weights sit in LDS at a time
 __device__ __forceinline__ float dpp_prev_lane(float v) {      // lane i <- lane i - 1 (lane 0: 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -285,6 +286,14 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
     unsigned off4[3];
     StripHalo h;
     strip_setup(valid, b, y, xs, W4, g.Cin, g.IH, g.IW, off4, h);
+#ifdef AGAN_STRIP_PACKED_PAIRS      // (diagnostic build only: the float2 / v_pk_fma_f32 form of profiles/r04_p16_analysis.txt section 7)
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    f32x2s a01[4][4], a23[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { a01[k][p] = f32x2s{0.f, 0.f}; a23[k][p] = f32x2s{0.f, 0.f}; }
+#else
     float acc[4][4][NC];                                // [class][lattice point][channel]
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int n = 0; n < NC; ++n) acc[k][p][n] = 0.f;
+#endif
     const size_t wcls = (size_t)g.K * g.Nld;            // K = Cin * 4
     __shared__ float4 wl[kStripCh * 16];                // [channel][class][r][t] x 4 floats
     u32x4s raw[3];
@@ -320,14 +330,34 @@ __global__ __launch_bounds__(256) void conv_small_dgrad4_strip_kernel(const void
                         const float4 w4 = wl[cc * 16 + k * 4 + r * 2 + t];
                         const float w[4] = {w4.x, w4.y, w4.z, w4.w};
                         const int row = py - r + 1, col = px - t + 1;          // dY row y' + OY[py] - r, column x' + OY[px] - t
+#ifdef AGAN_STRIP_PACKED_PAIRS
+                        const f32x2s w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const float x = v[row][p + col];
+                            a01[k][p] += w01 * x;
+                            if (NC >= 3) a23[k][p] += w23 * x;
+                        }
+                        (void)w;
+#else
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
 #pragma unroll
                             for (int n = 0; n < NC; ++n) acc[k][p][n] += w[n] * v[row][p + col];
+#endif
                     }
             }
         }
     }
+#ifdef AGAN_STRIP_PACKED_PAIRS
+    float acc[4][4][NC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int n = 0; n < NC; ++n) acc[k][p][n] = n < 2 ? a01[k][p][n & 1] : a23[k][p][n & 1];
+#endif
     if (CS > 1) {
         __shared__ float red[CS - 1 > 0 ? CS - 1 : 1][16 * NC][64];
         const int lane = threadIdx.x & 63;

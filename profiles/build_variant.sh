@@ -12,7 +12,7 @@ OBJS=""
 for o in conv conv_patch conv_p16 conv_wgrows conv_wino conv_small bn_act attention damsm heads comm; do
   if echo " $SRCS " | grep -q " $o.hip "; then
     EXTRA=""; [ "$o" = conv_small ] && EXTRA="-fno-slp-vectorize"      # (the shipped per-file flags: csrc/Makefile)
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $EXTRA $FLAGS -c $o.hip -o variants/${o}_$NAME.o \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops $EXTRA $FLAGS -c $o.hip -o variants/${o}_$NAME.o \
         2> >(grep -v "is not a recognized feature for this target" >&2)
     OBJS="$OBJS variants/${o}_$NAME.o"
   else
