@@ -192,7 +192,7 @@ def _run_metric_parity(bench, HF, mode):
             assert rel_err(hip[k], o32[k]) <= RTOL, k
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16+s16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16+s16"])
 def test_metric_config_step_is_bit_stable_run_to_run(mode):
     """The same first step from the same weights and inputs, four times: fake images, the gradients w.r.t. the three fake images and
     every generator and discriminator gradient must be IDENTICAL bit for bit ("bf16+s16": bf16 arithmetic with 16-bit activation storage).  The step runs its three discriminators on three streams, so kernels of
