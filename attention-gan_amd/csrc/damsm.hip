@@ -17,9 +17,8 @@ using namespace agan;
 #define AGAN_PRAGMA_(x) _Pragma(#x)
 #define AGAN_PRAGMA(x) AGAN_PRAGMA_(x)
 #define AGAN_PAIR_UNROLL AGAN_PRAGMA(unroll AGAN_PAIR_UNROLL_N)
-#ifndef AGAN_PAIR_MFMA_UNROLL
-#define AGAN_PAIR_MFMA_UNROLL 4
-#endif
+// (the d loops of the MFMA reductions below carry no unroll count: with a runtime trip count and a convergent instruction inside, the compiler refuses
+//  a counted unroll -- the pragma they used to carry only produced three "loop not unrolled" warnings per build)
 #ifndef AGAN_PAIR_MFMA_WAVES
 #define AGAN_PAIR_MFMA_WAVES 4
 #endif
@@ -217,7 +216,6 @@ __device__ __forceinline__ void mfma_region_rows(const float* __restrict__ fjP, 
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int col = min(wave * 64 + 4 * mi, kMS - 4);          // (regions beyond the padded row: clamped address, never stored)
     const float* fp = fjP + (size_t)kq * kMS + col;
-AGAN_PRAGMA(unroll AGAN_PAIR_MFMA_UNROLL)
     for (int d0 = 0; d0 < D; d0 += 4) {
         const float b = bm[d0 + kq][mi];                       // B[k = d][j = w]   (columns 12..15 read the next row: never stored)
         const f32x4 a = *reinterpret_cast<const f32x4*>(fp + (size_t)d0 * kMS);      // A[i][k = d] of the four tiles
@@ -244,7 +242,6 @@ __device__ __forceinline__ void mfma_channel_rows(const float* __restrict__ fjT,
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ft = fjT + wave * 64 + 4 * mi;
-AGAN_PRAGMA(unroll AGAN_PAIR_MFMA_UNROLL)
     for (int r0 = 0; r0 < kMS; r0 += 4) {
         const float b = bm[r0 + kq][mi];                        // B[k = r][j = w]
         const f32x4 a = *reinterpret_cast<const f32x4*>(ft + (size_t)min(r0 + kq, S - 1) * D);   // A[i][k = r] of the four tiles
